@@ -1,0 +1,99 @@
+/* vidar_hip.h — C ABI of libvidar_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for ViDAR's BEV-encode -> latent-render -> chamfer hot path.
+ * Every entry point takes raw DEVICE pointers + plain sizes + a hipStream_t
+ * (passed as void*; NULL = the legacy default stream) and returns 0 on success,
+ * a positive hipError_t code if a HIP call failed, or VIDAR_ERR_BAD_ARG.
+ * No torch types cross this boundary.  All calls are asynchronous on `stream`;
+ * unlike the reference (kernels on the legacy default stream followed by
+ * cudaDeviceSynchronize(), e.g. third_lib/dvxlr/dvxlr.cu:510) nothing here
+ * synchronises the device.  Outputs are written completely by the call
+ * (including the -1 / 0 padding the reference obtains from torch::ones/zeros),
+ * so callers may pass uninitialised buffers.
+ *
+ * Citations are file:line under the reference tree (OpenDriveLab/ViDAR @ v2).
+ */
+#ifndef VIDAR_HIP_H_
+#define VIDAR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIDAR_ERR_BAD_ARG (-22)
+
+/* ABI revision of this header; bumped whenever a signature changes. */
+int vidar_abi_version(void);
+
+/* ---------------------------------------------------------------------------
+ * third_lib/dvr  (pybind surface: third_lib/dvr/dvr.cpp:36-69)
+ *   sigma   [N,T,Z,Y,X] f32     origin [N,TO,3] f32 (voxel units)
+ *   points  [N,M,3]     f32     tindex [N,M]    f32 (frame id, <0 = padded ray)
+ * ------------------------------------------------------------------------- */
+int vidar_dvr_max_d(void);   /* 1446, third_lib/dvr/dvr.cu:9 */
+
+/* dvr.render_forward(sigma, origin, points, tindex, grid, phase_name) -> [pred_dist, gt_dist]
+ * third_lib/dvr/dvr.cu:65-383.  train_phase: 0 = "test", 1 = "train" (dvr.cu:361-366). */
+int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,
+                                 const float* tindex, float* pred_dist /*[N,M]*/,
+                                 float* gt_dist /*[N,M]*/, int N, int M, int T, int TO, int Z, int Y,
+                                 int X, int train_phase, void* stream);
+
+/* dvr.render(sigma, origin, points, tindex, loss_name) -> [pred_dist, gt_dist, grad_sigma]
+ * third_lib/dvr/dvr.cu:385-694.  loss_type: 0 = "l1" (and "bce"), 1 = "l2", 2 = "absrel"
+ * (dvr.cu:658-672).  grad_sigma [N,T,Z,Y,X] is zeroed by the call, then accumulated with
+ * fp32 hardware atomics (the reference's "+=" at dvr.cu:622 is racy). */
+int vidar_dvr_render_f32(const float* sigma, const float* origin, const float* points,
+                         const float* tindex, float* pred_dist, float* gt_dist, float* grad_sigma,
+                         int N, int M, int T, int TO, int Z, int Y, int X, int loss_type,
+                         void* stream);
+
+/* dvr.init / dvxlr.init(points, tindex, grid) -> occupancy [N,T,Z,Y,X]
+ * third_lib/dvr/dvr.cu:14-63,:705-738 == third_lib/dvxlr/dvxlr.cu:12-61,:528-561. */
+int vidar_dvr_init_f32(const float* points, const float* tindex, float* occupancy, int N, int M,
+                       int T, int Z, int Y, int X, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * third_lib/dvxlr  (pybind surface: dvxlr.cpp:34-65, dvxlr_v2.cpp:34-70)
+ * ------------------------------------------------------------------------- */
+int vidar_dvxlr_max_d(void); /* 1026, third_lib/dvxlr/dvxlr.cu:10 */
+
+/* dvxlr.render(sigma, origin, points, tindex) -> [pred_dist, gt_dist, dd_dsigma, indices]
+ * third_lib/dvxlr/dvxlr.cu:160-517.
+ *   dd_dsigma [N,M,1026] f32 (0-padded), indices [N,M,1026,3] f32 as (z,y,x) (0-padded). */
+int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float* points,
+                           const float* tindex, float* pred_dist, float* gt_dist, float* dd_dsigma,
+                           float* indices, int N, int M, int T, int TO, int Z, int Y, int X,
+                           void* stream);
+
+/* dvxlr.get_grad_sigma(elementwise_mult, indices, tindex, sigma_like) -> [grad_sigma]
+ * third_lib/dvxlr/dvxlr.cu:63-156.  L = elementwise_mult.size(2). grad_sigma zeroed by the call. */
+int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult /*[N,M,L]*/,
+                                   const float* indices /*[N,M,L,3]*/, const float* tindex,
+                                   float* grad_sigma /*[N,T,Z,Y,X]*/, int N, int M, int L, int T,
+                                   int Z, int Y, int X, void* stream);
+
+/* dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma_regul)
+ *   -> [pred_dist, gt_dist, dd_dsigma, indices, ray_pred, indicator]
+ * third_lib/dvxlr/dvxlr_v2.cu:119-493. indicator is -1-padded, 1 at the first sample whose
+ * exit distance reaches the un-clamped ray length (dvxlr_v2.cu:408-424). */
+int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float* points,
+                            const float* tindex, const float* sigma_regul, float* pred_dist,
+                            float* gt_dist, float* dd_dsigma, float* indices, float* ray_pred,
+                            float* indicator, int N, int M, int T, int TO, int Z, int Y, int X,
+                            void* stream);
+
+/* dvxlr_v2.get_grad_sigma_v2(em, indices, tindex, sigma_like, indicator, grad_ray_pred)
+ *   -> [grad_sigma, grad_sigma_regul]       third_lib/dvxlr/dvxlr_v2.cu:12-115 */
+int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* indices,
+                                    const float* tindex, const float* indicator,
+                                    const float* grad_ray_pred, float* grad_sigma,
+                                    float* grad_sigma_regul, int N, int M, int L, int T, int Z, int Y,
+                                    int X, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDAR_HIP_H_ */

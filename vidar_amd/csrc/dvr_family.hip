@@ -1,0 +1,542 @@
+// Differentiable voxel rendering kernels (dvr / dvxlr / dvxlr_v2) for gfx950.
+//
+// Replaces (behaviour, not code) the reference CUDA extensions
+//   third_lib/dvr/dvr.cu          : init :14-63, render_forward :65-383, render :385-694
+//   third_lib/dvxlr/dvxlr.cu      : get_grad_sigma :63-156, render :160-517, init :528-561
+//   third_lib/dvxlr/dvxlr_v2.cu   : get_grad_sigma_v2 :12-115, render_v2 :119-493
+//
+// Design (MI355X-first, not a translation):
+//  * The reference keeps 5-6 per-thread arrays of MAX_D doubles (53-75 KB of
+//    scratch per thread).  Here a ray keeps O(1) state: the march is an
+//    *online* recurrence.  With T_k = exp(-csd_k) and W_k = T_k (d_{k+1}-d_k):
+//        pred_dist      = d_0 + sum_k W_k                (summation by parts)
+//        dd_dsigma[i]   = -dt_i * sum_{k>=i} W_k         (suffix sum)
+//    so pass A computes the total S = sum W_k and pass B re-marches the ray and
+//    emits dt_i * (P_i - S) with the running prefix P_i.  No per-ray arrays,
+//    no scratch, registers only.
+//  * The "consecutive duplicate voxel" merge of dvxlr (dvxlr.cu:366-373) is a
+//    one-slot pending sample that is either widened or committed.
+//  * The kernel owns the padding of the API-mandated [N,M,MAX_D(,3)] rows: the
+//    live prefix is written by the owning lane, the tail is filled by the whole
+//    wave with coalesced stores, so callers pass torch.empty() buffers.
+//  * All traversal decisions are IEEE fp64 in the reference's operation order;
+//    this file must be compiled with -ffp-contract=off (see build.py).
+//  * one wave (64 rays) per workgroup so that M=30k rays spread over all CUs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <math.h>
+
+#include "vidar_hip.h"
+
+namespace {
+
+constexpr int kDvrMaxD = 1446;    // dvr.cu:9
+constexpr int kDvxlrMaxD = 1026;  // dvxlr.cu:10, dvxlr_v2.cu:10
+constexpr int kWave = 64;
+constexpr long kStepCap = 1L << 22;  // reference has no cap (it would hang); we bound every loop
+
+enum MarchMode : int {
+  kClassic = 0,        // dvr.render: first boundary v+(step<0?0:1), integer voxel path
+  kRounded = 1,        // dvr.render_forward: boundary v+(step<0?-1:1), path = round(position)
+  kRoundedMerged = 2,  // dvxlr / dvxlr_v2: kRounded + merge of consecutive duplicate voxels
+};
+
+struct Vol {
+  int T, TO, Z, Y, X;
+};
+
+struct RayIn {
+  double xo, yo, zo, xe, ye, ze;
+  int ts;      // time slice of sigma
+  bool valid;  // false: padded ray (tindex < 0) or tindex out of range
+};
+
+__device__ __forceinline__ RayIn load_ray(const float* __restrict__ origin,
+                                          const float* __restrict__ points,
+                                          const float* __restrict__ tindex, int n, int c, int M,
+                                          const Vol& v) {
+  RayIn r;
+  const float t = tindex[(size_t)n * M + c];
+  r.valid = !(t < 0.f) && (t == t);
+  long ti = r.valid ? (long)t : 0;
+  if (!(v.T == 1 || ti < v.T) || ti >= v.TO) r.valid = false;  // reference: device assert
+  if (!r.valid) ti = 0;
+  r.ts = (v.T == 1) ? 0 : (int)ti;
+  const float* o = origin + ((size_t)n * v.TO + ti) * 3;
+  const float* p = points + ((size_t)n * M + c) * 3;
+  r.xo = o[0]; r.yo = o[1]; r.zo = o[2];
+  r.xe = p[0]; r.ye = p[1]; r.ze = p[2];
+  return r;
+}
+
+// Amanatides-Woo traversal with the reference's modifications.  Sink::sample is
+// called once per step spent inside the volume, in order, with the voxel the
+// reference would record, the exit distance _d of that step and the previous
+// step's exit distance.  Returns the un-clamped ray length.
+template <int MODE, class Sink>
+__device__ __forceinline__ double march(const RayIn& r, const Vol& g, Sink& sink) {
+  int vx = (int)r.xo, vy = (int)r.yo, vz = (int)r.zo;
+  double px = (double)vx, py = (double)vy, pz = (double)vz;
+  const double rx = r.xe - r.xo, ry = r.ye - r.yo, rz = r.ze - r.zo;
+  const double len = sqrt(rx * rx + ry * ry + rz * rz);
+  const double dx = rx / len, dy = ry / len, dz = rz / len;
+  const int sx = (dx >= 0) ? 1 : -1, sy = (dy >= 0) ? 1 : -1, sz = (dz >= 0) ? 1 : -1;
+  const int back = (MODE == kClassic) ? 0 : -1;
+  const double bx = vx + (sx < 0 ? back : 1);
+  const double by = vy + (sy < 0 ? back : 1);
+  const double bz = vz + (sz < 0 ? back : 1);
+  double tx = (dx != 0) ? (bx - r.xo) / dx : DBL_MAX;
+  double ty = (dy != 0) ? (by - r.yo) / dy : DBL_MAX;
+  double tz = (dz != 0) ? (bz - r.zo) / dz : DBL_MAX;
+  const double ddx = (dx != 0) ? sx / dx : DBL_MAX;
+  const double ddy = (dy != 0) ? sy / dy : DBL_MAX;
+  const double ddz = (dz != 0) ? sz / dz : DBL_MAX;
+
+  double last_d = 0.0;
+  bool was_inside = false;
+  for (long step = 0; step < kStepCap; ++step) {
+    const bool inside = (0 <= vx && vx < g.X) && (0 <= vy && vy < g.Y) && (0 <= vz && vz < g.Z);
+    int qx = vx, qy = vy, qz = vz;
+    if (inside) {
+      was_inside = true;
+      if (MODE != kClassic) {
+        qx = (int)round(px); qx = qx < g.X ? qx : g.X - 1; qx = qx >= 0 ? qx : 0;
+        qy = (int)round(py); qy = qy < g.Y ? qy : g.Y - 1; qy = qy >= 0 ? qy : 0;
+        qz = (int)round(pz); qz = qz < g.Z ? qz : g.Z - 1; qz = qz >= 0 ? qz : 0;
+      }
+    } else if (was_inside) {
+      break;
+    } else if (last_d > len) {
+      break;
+    }
+    double d;
+    if (tx < ty) {
+      if (tx < tz) { d = tx; vx += sx; tx += ddx; }
+      else         { d = tz; vz += sz; tz += ddz; }
+    } else {
+      if (ty < tz) { d = ty; vy += sy; ty += ddy; }
+      else         { d = tz; vz += sz; tz += ddz; }
+    }
+    if (MODE != kClassic) {
+      const double adv = fmax(0.0, d - last_d);
+      px += adv * dx; py += adv * dy; pz += adv * dz;
+    }
+    if (inside) {
+      if (!sink.sample(qx, qy, qz, d, last_d)) break;
+    }
+    last_d = d;
+  }
+  sink.finish();
+  return len;
+}
+
+// Online integrator shared by every variant.  Emit::commit(k, x,y,z, d, dt, P_k)
+// is called once per *final* sample k in order (P_k = prefix of W before k).
+template <int MODE, int MAXD, class Emit>
+struct Integrator {
+  const float* __restrict__ sig;  // sigma[n][ts] slice
+  int Y, X;
+  Emit& emit;
+  // committed state
+  int k = 0;
+  double csd = 0.0, Tprev = 1.0, dprev = 0.0, d0 = 0.0, S = 0.0;
+  // pending sample (merged mode only)
+  bool pending = false;
+  int ux = 0, uy = 0, uz = 0;
+  double ud = 0.0, udt = 0.0;
+
+  __device__ __forceinline__ Integrator(const float* s, int Y_, int X_, Emit& e)
+      : sig(s), Y(Y_), X(X_), emit(e) {}
+
+  __device__ __forceinline__ void commit(int x, int y, int z, double d, double dt) {
+    const double sg = (double)sig[((size_t)z * Y + y) * X + x];
+    if (k == 0) {
+      d0 = d;
+    } else {
+      S += Tprev * (d - dprev);
+    }
+    emit.commit(k, x, y, z, d, dt, S);
+    csd = (k == 0) ? sg * dt : csd + sg * dt;
+    Tprev = exp(-csd);
+    dprev = d;
+    ++k;
+  }
+
+  __device__ __forceinline__ bool sample(int x, int y, int z, double d, double last_d) {
+    if (MODE == kRoundedMerged) {
+      if (pending && x == ux && y == uy && z == uz) {
+        // dvxlr.cu:366-377: drop the previous sample, rewind last_d by its dt
+        udt = fmax(0.0, d - (last_d - udt));
+        ud = d;
+        return true;
+      }
+      if (pending) commit(ux, uy, uz, ud, udt);
+      if (k >= MAXD) { pending = false; return false; }
+      ux = x; uy = y; uz = z; ud = d; udt = fmax(0.0, d - last_d);
+      pending = true;
+      return true;
+    } else {
+      if (k >= MAXD) return false;
+      commit(x, y, z, d, fmax(0.0, d - last_d));
+      return true;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (MODE == kRoundedMerged && pending) { commit(ux, uy, uz, ud, udt); pending = false; }
+  }
+  // after finish(): count = k, p_out = Tprev, max_d = dprev, pred = d0 + S
+};
+
+struct NoEmit {
+  __device__ __forceinline__ void commit(int, int, int, int, double, double, double) {}
+};
+
+// ----------------------------------------------------------------------------------------------
+// dvr.render_forward
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void dvr_render_forward_kernel(
+    const float* __restrict__ sigma, const float* __restrict__ origin,
+    const float* __restrict__ points, const float* __restrict__ tindex,
+    float* __restrict__ pred_dist, float* __restrict__ gt_dist, int M, Vol g, int train_phase) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * kWave + threadIdx.x;
+  if (c >= M) return;
+  float pred = -1.f, gt = -1.f;
+  const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
+  if (r.valid) {
+    NoEmit ne;
+    const size_t vol = (size_t)g.Z * g.Y * g.X;
+    Integrator<kRounded, kDvrMaxD, NoEmit> integ(sigma + ((size_t)n * g.T + r.ts) * vol, g.Y, g.X, ne);
+    const double len = march<kRounded>(r, g, integ);
+    if (integ.k > 0) {
+      pred = (float)(integ.d0 + integ.S);
+      gt = (float)(train_phase ? fmin(len, integ.dprev) : len);
+    }
+  }
+  pred_dist[(size_t)n * M + c] = pred;
+  gt_dist[(size_t)n * M + c] = gt;
+}
+
+// ----------------------------------------------------------------------------------------------
+// dvr.render (fused loss gradient, dvr.cu:594-623).  Reference accumulates with a racy "+=";
+// we use hardware fp32 atomics, which is the race-free reading of the same sum.
+// ----------------------------------------------------------------------------------------------
+struct GradScatter {
+  float* __restrict__ grad;  // grad_sigma[n][ts] slice
+  int Y, X;
+  double S_total, dl_dd;
+  __device__ __forceinline__ void commit(int, int x, int y, int z, double, double dt, double P) {
+    const double g = dl_dd * (dt * (P - S_total));
+    if (g != 0.0) unsafeAtomicAdd(grad + ((size_t)z * Y + y) * X + x, (float)g);
+  }
+};
+
+__global__ __launch_bounds__(kWave) void dvr_render_kernel(
+    const float* __restrict__ sigma, const float* __restrict__ origin,
+    const float* __restrict__ points, const float* __restrict__ tindex,
+    float* __restrict__ pred_dist, float* __restrict__ gt_dist, float* __restrict__ grad_sigma,
+    int M, Vol g, int loss_type) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * kWave + threadIdx.x;
+  if (c >= M) return;
+  float pred = -1.f, gt = -1.f;
+  const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
+  if (r.valid) {
+    const size_t vol = (size_t)g.Z * g.Y * g.X;
+    const size_t slice = ((size_t)n * g.T + r.ts) * vol;
+    NoEmit ne;
+    Integrator<kClassic, kDvrMaxD, NoEmit> a(sigma + slice, g.Y, g.X, ne);
+    const double len = march<kClassic>(r, g, a);
+    if (a.k > 0) {
+      const double exp_d = a.d0 + a.S;
+      const double gt_d = fmin(len, a.dprev);
+      pred = (float)exp_d;
+      gt = (float)gt_d;
+      double dl = 1.0;
+      if (loss_type == 0) dl = (exp_d >= gt_d) ? 1.0 : -1.0;
+      else if (loss_type == 1) dl = exp_d - gt_d;
+      else if (loss_type == 2) dl = (exp_d >= gt_d) ? (1.0 / gt_d) : -(1.0 / gt_d);
+      GradScatter gs{grad_sigma + slice, g.Y, g.X, a.S, dl};
+      Integrator<kClassic, kDvrMaxD, GradScatter> b(sigma + slice, g.Y, g.X, gs);
+      march<kClassic>(r, g, b);
+    }
+  }
+  pred_dist[(size_t)n * M + c] = pred;
+  gt_dist[(size_t)n * M + c] = gt;
+}
+
+// ----------------------------------------------------------------------------------------------
+// dvxlr.render / dvxlr_v2.render_v2
+// ----------------------------------------------------------------------------------------------
+template <bool V2>
+struct RowWriter {
+  float* __restrict__ dd;    // dd_dsigma[n][c]
+  float* __restrict__ idx;   // indices[n][c]
+  float* __restrict__ rp;    // ray_pred[n][c]     (V2)
+  float* __restrict__ ind;   // indicator[n][c]    (V2)
+  const float* __restrict__ regul;  // sigma_regul[n][ts] (V2)
+  int Y, X;
+  double S_total, true_len;
+  bool reached = false;
+  __device__ __forceinline__ void commit(int k, int x, int y, int z, double d, double dt, double P) {
+    dd[k] = (float)(dt * (P - S_total));
+    idx[3 * k + 0] = (float)z;
+    idx[3 * k + 1] = (float)y;
+    idx[3 * k + 2] = (float)x;
+    if (V2) {
+      float flag = 0.f;
+      if (!reached && d >= true_len) { flag = 1.f; reached = true; }
+      ind[k] = flag;
+      rp[k] = regul[((size_t)z * Y + y) * X + x];
+    }
+  }
+};
+
+// whole wave pads rows [cnt, MAXD) of the 64 rays it owns with `fill`
+__device__ __forceinline__ void pad_rows(float* __restrict__ base, size_t row_elems, int per, int cnt,
+                                         int c0, int M, float fill) {
+  const int lane = threadIdx.x;
+  for (int r = 0; r < kWave; ++r) {
+    const int cr = c0 + r;
+    if (cr >= M) break;
+    const int k = __shfl(cnt, r, kWave);
+    float* row = base + (size_t)cr * row_elems;
+    const int begin = k * per, end = (int)row_elems;
+    for (int i = begin + lane; i < end; i += kWave) row[i] = fill;
+  }
+}
+
+template <bool V2>
+__global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
+    const float* __restrict__ sigma, const float* __restrict__ sigma_regul,
+    const float* __restrict__ origin, const float* __restrict__ points,
+    const float* __restrict__ tindex, float* __restrict__ pred_dist, float* __restrict__ gt_dist,
+    float* __restrict__ dd_dsigma, float* __restrict__ indices, float* __restrict__ ray_pred,
+    float* __restrict__ indicator, int M, Vol g) {
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.x * kWave;
+  const int c = c0 + threadIdx.x;
+  int count = 0;
+  const size_t rowbase = (size_t)n * M;
+  if (c < M) {
+    float pred = -1.f, gt = -1.f;
+    const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
+    if (r.valid) {
+      const size_t vol = (size_t)g.Z * g.Y * g.X;
+      const size_t slice = ((size_t)n * g.T + r.ts) * vol;
+      NoEmit ne;
+      Integrator<kRoundedMerged, kDvxlrMaxD, NoEmit> a(sigma + slice, g.Y, g.X, ne);
+      const double len = march<kRoundedMerged>(r, g, a);
+      if (a.k > 0) {
+        pred = (float)(a.d0 + a.S);
+        gt = (float)fmin(len, a.dprev);
+        RowWriter<V2> w;
+        w.dd = dd_dsigma + (rowbase + c) * kDvxlrMaxD;
+        w.idx = indices + (rowbase + c) * kDvxlrMaxD * 3;
+        w.rp = V2 ? ray_pred + (rowbase + c) * kDvxlrMaxD : nullptr;
+        w.ind = V2 ? indicator + (rowbase + c) * kDvxlrMaxD : nullptr;
+        w.regul = V2 ? sigma_regul + slice : nullptr;
+        w.Y = g.Y; w.X = g.X; w.S_total = a.S; w.true_len = len;
+        Integrator<kRoundedMerged, kDvxlrMaxD, RowWriter<V2>> b(sigma + slice, g.Y, g.X, w);
+        march<kRoundedMerged>(r, g, b);
+        count = b.k;
+      }
+    }
+    pred_dist[rowbase + c] = pred;
+    gt_dist[rowbase + c] = gt;
+  }
+  // tails (and whole rows of rays that never met the volume)
+  pad_rows(dd_dsigma + rowbase * kDvxlrMaxD, kDvxlrMaxD, 1, count, c0, M, 0.f);
+  pad_rows(indices + rowbase * kDvxlrMaxD * 3, (size_t)kDvxlrMaxD * 3, 3, count, c0, M, 0.f);
+  if (V2) {
+    pad_rows(ray_pred + rowbase * kDvxlrMaxD, kDvxlrMaxD, 1, count, c0, M, 0.f);
+    pad_rows(indicator + rowbase * kDvxlrMaxD, kDvxlrMaxD, 1, count, c0, M, -1.f);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// get_grad_sigma{,_v2}: one wave per ray, the padded rows are streamed with coalesced loads.
+// Zero contributions are skipped (adding +0 is the identity), NaNs are propagated like the reference.
+// ----------------------------------------------------------------------------------------------
+template <bool V2>
+__global__ __launch_bounds__(256) void dvxlr_scatter_kernel(
+    const float* __restrict__ em, const float* __restrict__ indices,
+    const float* __restrict__ tindex, const float* __restrict__ indicator,
+    const float* __restrict__ grad_ray_pred, float* __restrict__ grad_sigma,
+    float* __restrict__ grad_regul, int M, int L, Vol g) {
+  const int n = blockIdx.y;
+  const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+  const int c = blockIdx.x * (256 / kWave) + wave;
+  if (c >= M) return;
+  const float t = tindex[(size_t)n * M + c];
+  if (t < 0.f || t != t) return;
+  const long ti = (long)t;
+  if (!(g.T == 1 || ti < g.T)) return;
+  const int ts = (g.T == 1) ? 0 : (int)ti;
+  const size_t vol = (size_t)g.Z * g.Y * g.X;
+  float* gs = grad_sigma + ((size_t)n * g.T + ts) * vol;
+  float* gr = V2 ? grad_regul + ((size_t)n * g.T + ts) * vol : nullptr;
+  const size_t row = ((size_t)n * M + c) * L;
+  for (int i = lane; i < L; i += kWave) {
+    const float v = em[row + i];
+    bool live = (v != 0.f);
+    float rv = 0.f;
+    if (V2) {
+      if (indicator[row + i] >= 0.f) {
+        rv = grad_ray_pred[row + i];
+        live = live || (rv != 0.f);
+      }
+    }
+    if (!live) continue;
+    const int z = (int)indices[(row + i) * 3 + 0];
+    const int y = (int)indices[(row + i) * 3 + 1];
+    const int x = (int)indices[(row + i) * 3 + 2];
+    const size_t o = ((size_t)z * g.Y + y) * g.X + x;
+    if (v != 0.f) unsafeAtomicAdd(gs + o, v);
+    if (V2 && rv != 0.f) unsafeAtomicAdd(gr + o, rv);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// init (occupancy rasterisation, dvr.cu:14-63 == dvxlr.cu:12-61)
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dvr_init_kernel(const float* __restrict__ points,
+                                                       const float* __restrict__ tindex,
+                                                       float* __restrict__ occupancy, int M, Vol g) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= M) return;
+  const float t = tindex[(size_t)n * M + c];
+  if (t < 0.f || t != t) return;
+  const long ti = (long)t;
+  if (!(g.T == 1 || ti < g.T)) return;
+  const int ts = (g.T == 1) ? 0 : (int)ti;
+  const float* p = points + ((size_t)n * M + c) * 3;
+  const int vx = (int)p[0], vy = (int)p[1], vz = (int)p[2];
+  if (0 <= vx && vx < g.X && 0 <= vy && vy < g.Y && 0 <= vz && vz < g.Z)
+    occupancy[((((size_t)n * g.T + ts) * g.Z + vz) * g.Y + vy) * g.X + vx] = 1.f;
+}
+
+inline int hip_ret() { return (int)hipGetLastError(); }
+inline bool bad_dims(int N, int M, int T, int Z, int Y, int X) {
+  return N < 0 || M < 0 || T <= 0 || Z <= 0 || Y <= 0 || X <= 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vidar_dvr_max_d(void) { return kDvrMaxD; }
+int vidar_dvxlr_max_d(void) { return kDvxlrMaxD; }
+
+int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,
+                                 const float* tindex, float* pred_dist, float* gt_dist, int N, int M,
+                                 int T, int TO, int Z, int Y, int X, int train_phase, void* stream) {
+  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0 || (train_phase != 0 && train_phase != 1))
+    return VIDAR_ERR_BAD_ARG;
+  if (N == 0 || M == 0) return 0;
+  Vol g{T, TO, Z, Y, X};
+  dim3 grid((M + kWave - 1) / kWave, N);
+  hipLaunchKernelGGL(dvr_render_forward_kernel, grid, dim3(kWave), 0, (hipStream_t)stream, sigma,
+                     origin, points, tindex, pred_dist, gt_dist, M, g, train_phase);
+  return hip_ret();
+}
+
+int vidar_dvr_render_f32(const float* sigma, const float* origin, const float* points,
+                         const float* tindex, float* pred_dist, float* gt_dist, float* grad_sigma,
+                         int N, int M, int T, int TO, int Z, int Y, int X, int loss_type,
+                         void* stream) {
+  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0 || loss_type < 0 || loss_type > 2)
+    return VIDAR_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * (size_t)N * T * Z * Y * X,
+                                (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (N == 0 || M == 0) return 0;
+  Vol g{T, TO, Z, Y, X};
+  dim3 grid((M + kWave - 1) / kWave, N);
+  hipLaunchKernelGGL(dvr_render_kernel, grid, dim3(kWave), 0, (hipStream_t)stream, sigma, origin,
+                     points, tindex, pred_dist, gt_dist, grad_sigma, M, g, loss_type);
+  return hip_ret();
+}
+
+int vidar_dvr_init_f32(const float* points, const float* tindex, float* occupancy, int N, int M,
+                       int T, int Z, int Y, int X, void* stream) {
+  if (bad_dims(N, M, T, Z, Y, X)) return VIDAR_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(occupancy, 0, sizeof(float) * (size_t)N * T * Z * Y * X,
+                                (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (N == 0 || M == 0) return 0;
+  Vol g{T, T, Z, Y, X};
+  dim3 grid((M + 255) / 256, N);
+  hipLaunchKernelGGL(dvr_init_kernel, grid, dim3(256), 0, (hipStream_t)stream, points, tindex,
+                     occupancy, M, g);
+  return hip_ret();
+}
+
+int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float* points,
+                           const float* tindex, float* pred_dist, float* gt_dist, float* dd_dsigma,
+                           float* indices, int N, int M, int T, int TO, int Z, int Y, int X,
+                           void* stream) {
+  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0) return VIDAR_ERR_BAD_ARG;
+  if (N == 0 || M == 0) return 0;
+  Vol g{T, TO, Z, Y, X};
+  dim3 grid((M + kWave - 1) / kWave, N);
+  hipLaunchKernelGGL(dvxlr_render_kernel<false>, grid, dim3(kWave), 0, (hipStream_t)stream, sigma,
+                     (const float*)nullptr, origin, points, tindex, pred_dist, gt_dist, dd_dsigma,
+                     indices, (float*)nullptr, (float*)nullptr, M, g);
+  return hip_ret();
+}
+
+int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float* points,
+                            const float* tindex, const float* sigma_regul, float* pred_dist,
+                            float* gt_dist, float* dd_dsigma, float* indices, float* ray_pred,
+                            float* indicator, int N, int M, int T, int TO, int Z, int Y, int X,
+                            void* stream) {
+  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0) return VIDAR_ERR_BAD_ARG;
+  if (N == 0 || M == 0) return 0;
+  Vol g{T, TO, Z, Y, X};
+  dim3 grid((M + kWave - 1) / kWave, N);
+  hipLaunchKernelGGL(dvxlr_render_kernel<true>, grid, dim3(kWave), 0, (hipStream_t)stream, sigma,
+                     sigma_regul, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices,
+                     ray_pred, indicator, M, g);
+  return hip_ret();
+}
+
+int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult, const float* indices,
+                                   const float* tindex, float* grad_sigma, int N, int M, int L, int T,
+                                   int Z, int Y, int X, void* stream) {
+  if (bad_dims(N, M, T, Z, Y, X) || L < 0) return VIDAR_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * (size_t)N * T * Z * Y * X,
+                                (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (N == 0 || M == 0 || L == 0) return 0;
+  Vol g{T, T, Z, Y, X};
+  dim3 grid((M + 3) / 4, N);
+  hipLaunchKernelGGL(dvxlr_scatter_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                     elementwise_mult, indices, tindex, (const float*)nullptr, (const float*)nullptr,
+                     grad_sigma, (float*)nullptr, M, L, g);
+  return hip_ret();
+}
+
+int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* indices,
+                                    const float* tindex, const float* indicator,
+                                    const float* grad_ray_pred, float* grad_sigma,
+                                    float* grad_sigma_regul, int N, int M, int L, int T, int Z, int Y,
+                                    int X, void* stream) {
+  if (bad_dims(N, M, T, Z, Y, X) || L < 0) return VIDAR_ERR_BAD_ARG;
+  const size_t bytes = sizeof(float) * (size_t)N * T * Z * Y * X;
+  hipError_t e = hipMemsetAsync(grad_sigma, 0, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(grad_sigma_regul, 0, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  if (N == 0 || M == 0 || L == 0) return 0;
+  Vol g{T, T, Z, Y, X};
+  dim3 grid((M + 3) / 4, N);
+  hipLaunchKernelGGL(dvxlr_scatter_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                     elementwise_mult, indices, tindex, indicator, grad_ray_pred, grad_sigma,
+                     grad_sigma_regul, M, L, g);
+  return hip_ret();
+}
+
+}  // extern "C"
