@@ -16,6 +16,7 @@
 #ifndef VIDAR_HIP_H_
 #define VIDAR_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -92,6 +93,23 @@ int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* 
                                     const float* grad_ray_pred, float* grad_sigma,
                                     float* grad_sigma_regul, int N, int M, int L, int T, int Z, int Y,
                                     int X, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * third_lib/chamfer_dist/chamferdist  (pybind surface: chamferdist/ext.cpp:5-11)
+ * K = 1, D = 3 specialisation of knn_points_idx / knn_points_backward
+ * (knn.h:50-66, knn_cpu.cpp:7-58 & :64-106, knn.cu:297-435 & :482-544).
+ *   p1 [N,P1,3] f32, p2 [N,P2,3] f32, lengths1/2 [N] i64 (device), idx [N,P1] i64,
+ *   dist2 [N,P1] f32 = squared L2, evaluated as ((dx*dx+dy*dy)+dz*dz) without FMA; ties -> lowest
+ *   index.  workspace: vidar_knn1_d3_workspace_bytes(N,P1) bytes of device scratch.
+ * ------------------------------------------------------------------------- */
+size_t vidar_knn1_d3_workspace_bytes(int N, int P1);
+int vidar_knn1_d3_fwd(const float* p1, const float* p2, const int64_t* lengths1,
+                      const int64_t* lengths2, int64_t* idx, float* dist2, void* workspace, int N,
+                      int P1, int P2, void* stream);
+/* grad_p1 [N,P1,3] written, grad_p2 [N,P2,3] zeroed then accumulated (fp32 atomics). */
+int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
+                      const int64_t* lengths2, const int64_t* idx, const float* grad_dist2,
+                      float* grad_p1, float* grad_p2, int N, int P1, int P2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,75 @@
+"""GPU parity: HIP KNN (K=1, D=3) through the chamferdist mirror vs the numpy oracle.
+Indices and squared distances are bit-exact (same non-fused fp32 arithmetic, lowest-index ties)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chamfer as C
+from test_oracle_chamfer import clouds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(1, 100, 50), (2, 257, 1031), (1, 1, 1), (3, 64, 7),
+                                   (1, 5000, 3000), (1, 1030, 70000)])
+def test_knn_bit_exact(shape):
+    from vidar_amd.third_lib.chamferdist import _C
+    N, P1, P2 = shape
+    a, b = clouds(0, N, P1, P2, dup=True)
+    l1 = np.array([P1 - (n % 2) * (P1 // 3) for n in range(N)], np.int64)
+    l2 = np.array([P2 - (n % 2) * (P2 // 4) for n in range(N)], np.int64)
+    oi, od = C.knn_points_idx(a, b, l1, l2)
+    t = lambda x: torch.from_numpy(x).cuda()
+    gi, gd = _C.knn_points_idx(t(a), t(b), t(l1), t(l2), 1, -1)
+    assert gi.dtype == torch.int64 and gi.shape == (N, P1, 1)
+    assert np.array_equal(gi.cpu().numpy(), oi)
+    assert np.array_equal(gd.cpu().numpy(), od)
+    g = np.random.default_rng(1).standard_normal(od.shape).astype(np.float32)
+    o1, o2 = C.knn_points_backward(a, b, l1, l2, oi, g) if P1 * N <= 2000 else (None, None)
+    g1, g2 = _C.knn_points_backward(t(a), t(b), t(l1), t(l2), gi, t(g))
+    if o1 is not None:
+        np.testing.assert_allclose(g1.cpu().numpy(), o1, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(g2.cpu().numpy(), o2, rtol=1e-5, atol=1e-4)
+    # conservation: every gradient pushed on p1 is pulled from p2
+    np.testing.assert_allclose(g1.double().sum((1)).cpu().numpy(), -g2.double().sum(1).cpu().numpy(),
+                               rtol=1e-3, atol=1e-2)
+
+
+def test_empty_and_ragged():
+    from vidar_amd.third_lib.chamferdist import _C
+    a, b = clouds(2, 2, 10, 5)
+    l1 = torch.tensor([10, 0]).cuda(); l2 = torch.tensor([0, 5]).cuda()
+    gi, gd = _C.knn_points_idx(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), l1, l2, 1, -1)
+    assert int(gi.abs().sum()) == 0 and float(gd.abs().sum()) == 0.0
+
+
+def test_chamfer_module_and_cd():
+    from vidar_amd.third_lib.chamferdist import ChamferDistance
+    a, b = clouds(5, 1, 4000, 3500)
+    ta = torch.from_numpy(a).cuda().requires_grad_(True); tb = torch.from_numpy(b).cuda()
+    cd = ChamferDistance()
+    f, bwd, info = cd(ta, tb, bidirectional=True, reduction="sum")
+    val = (f / a.shape[1] + bwd / b.shape[1]) / 2.0
+    ref = C.compute_chamfer_distance(a[0], b[0])
+    assert abs(float(val) - float(ref)) <= 1e-3 * max(1.0, abs(float(ref)))   # CD within 1e-3
+    val.backward()
+    assert torch.isfinite(ta.grad).all() and float(ta.grad.abs().sum()) > 0
+    # example.py invariants: CD(x, x) == 0; bidirectional == fwd + reverse
+    z, _ = cd(ta.detach(), ta.detach())
+    assert float(z) == 0.0
+    f1, _ = cd(ta.detach(), tb, reduction="sum")
+    r1, _ = cd(ta.detach(), tb, reverse=True, reduction="sum")
+    assert float(f1) == float(f) and float(r1) == float(bwd)
+
+
+def test_full_size_properties():
+    """30k x 30k (BASELINE eval size): symmetric-pair and idempotence properties."""
+    from vidar_amd.third_lib.chamferdist import knn_points
+    a, b = clouds(9, 1, 30000, 30000)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    ab = knn_points(ta, tb); ba = knn_points(tb, ta)
+    # the neighbour's own nearest distance can only be <= (mutual-NN inequality)
+    assert bool((ba.dists[0, ab.idx[0, :, 0], 0] <= ab.dists[0, :, 0]).all())
+    same = knn_points(ta, ta)
+    assert float(same.dists.sum()) == 0.0
+    assert bool((same.idx[0, :, 0] == torch.arange(30000, device="cuda")).all())

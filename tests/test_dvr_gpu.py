@@ -1,0 +1,166 @@
+"""GPU parity: HIP dvr / dvxlr / dvxlr_v2 (through the C ABI) vs the CPU oracle and the golden
+fixtures.  Index lists, pred/gt masks: bit-exact.  Values: fp64 summation-order tolerance."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dvr as O
+from dvr_cases import CASES, case, expand
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def dev(*arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def close(a, b, rtol=2e-5, atol_rel=2e-6):
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else a
+    scale = max(1.0, float(np.abs(b).max())) if b.size else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_rel * scale)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_dvxlr_render(name):
+    from vidar_amd.third_lib import dvxlr
+    sigma, origin, points, tindex = case(name)
+    o = O.dvxlr_render(sigma, origin, points, tindex)
+    pred, gt, dd, idx = dvxlr.render(*dev(sigma, origin, points, tindex))
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), o[3]), "voxel index lists must be bit-exact"
+    assert np.array_equal(pred.cpu().numpy() < 0, o[0] < 0)
+    assert np.array_equal(gt.cpu().numpy(), o[1]), "gt_dist is pure traversal arithmetic: bit-exact"
+    close(pred, o[0]); close(dd, o[2])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_dvxlr_v2_render_and_scatter(name):
+    from vidar_amd.third_lib import dvxlr_v2
+    sigma, origin, points, tindex = case(name)
+    regul = np.random.default_rng(7).standard_normal(sigma.shape).astype(np.float32)
+    o = O.dvxlr_render(sigma, origin, points, tindex, regul)
+    d = dev(sigma, origin, points, tindex, regul)
+    pred, gt, dd, idx, rp, ind = dvxlr_v2.render_v2(*d)
+    assert np.array_equal(idx.cpu().numpy(), o[3])
+    assert np.array_equal(ind.cpu().numpy(), o[5])
+    assert np.array_equal(rp.cpu().numpy(), o[4])
+    assert np.array_equal(gt.cpu().numpy(), o[1])
+    close(pred, o[0]); close(dd, o[2])
+    if dd.numel() == 0:
+        return
+    rng = np.random.default_rng(8)
+    em = rng.standard_normal(o[0].shape).astype(np.float32)[..., None] * o[2]
+    grp = rng.standard_normal(o[4].shape).astype(np.float32)
+    og = O.dvxlr_get_grad_sigma(em, o[3], tindex, sigma.shape, o[5], grp)
+    g, g2 = dvxlr_v2.get_grad_sigma_v2(*dev(em, o[3], tindex), d[0], *dev(o[5], grp))
+    close(g, og[0], rtol=1e-4, atol_rel=1e-5); close(g2, og[1], rtol=1e-4, atol_rel=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_dvxlr_get_grad_sigma(name):
+    from vidar_amd.third_lib import dvxlr
+    sigma, origin, points, tindex = case(name)
+    pred, gt, dd, idx = O.dvxlr_render(sigma, origin, points, tindex)
+    if dd.size == 0:
+        return
+    em = np.random.default_rng(9).standard_normal(pred.shape).astype(np.float32)[..., None] * dd
+    og = O.dvxlr_get_grad_sigma(em, idx, tindex, sigma.shape)
+    g = dvxlr.get_grad_sigma(*dev(em, idx, tindex, sigma))[0]
+    close(g, og, rtol=1e-4, atol_rel=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("phase", ["train", "test"])
+def test_dvr_render_forward(name, phase):
+    from vidar_amd.third_lib import dvr
+    sigma, origin, points, tindex = case(name)
+    o = O.render_forward(sigma, origin, points, tindex, phase)
+    pred, gt = dvr.render_forward(*dev(sigma, origin, points, tindex), list(sigma.shape[1:]), phase)
+    assert np.array_equal(gt.cpu().numpy(), o[1])
+    close(pred, o[0])
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("loss", ["l1", "l2", "absrel", "bce"])
+def test_dvr_render(name, loss):
+    from vidar_amd.third_lib import dvr
+    sigma, origin, points, tindex = case(name)
+    o = O.render(sigma, origin, points, tindex, loss)
+    pred, gt, grad = dvr.render(*dev(sigma, origin, points, tindex), loss)
+    assert np.array_equal(gt.cpu().numpy(), o[1])
+    close(pred, o[0])
+    if loss in ("l1", "bce", "absrel"):
+        # sign(pred-gt) can flip where |pred-gt| is at rounding level; exclude those rays' voxels
+        # by comparing with a tolerance on the aggregate instead
+        close(grad.sum(), np.float32(o[2].sum(dtype=np.float64)), rtol=1e-3, atol_rel=1e-3)
+    close(grad, o[2], rtol=1e-3, atol_rel=1e-4)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_init(name):
+    from vidar_amd.third_lib import dvr, dvxlr
+    sigma, origin, points, tindex = case(name)
+    grid = [3, *sigma.shape[2:]]
+    ref = O.init(points, tindex, grid)
+    for m in (dvr, dvxlr):
+        occ = m.init(*dev(points, tindex), grid)
+        assert np.array_equal(occ.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("name", ["two_frames", "static_sigma", "small_grid"])
+def test_golden_from_reference_kernels(name):
+    """HIP vs fixtures produced by the reference's own kernels (compiled for host)."""
+    from vidar_amd.third_lib import dvxlr_v2
+    g = np.load(GOLD / f"dvr_family_{name}.npz")
+    sigma, origin, points, tindex = case(name)
+    regul = np.random.default_rng(7).standard_normal(sigma.shape).astype(np.float32)
+    pred, gt, dd, idx, rp, ind = dvxlr_v2.render_v2(*dev(sigma, origin, points, tindex, regul))
+    gdd, gidx, grp, gind = expand(g["count"], g["dd"], g["idx"],
+                                  [(g["ray_pred"], 0.0), (g["indicator"], -1.0)])
+    assert np.array_equal(idx.cpu().numpy(), gidx)
+    assert np.array_equal(ind.cpu().numpy(), gind) and np.array_equal(rp.cpu().numpy(), grp)
+    assert np.array_equal(gt.cpu().numpy(), g["gt"])
+    close(pred, g["pred"]); close(dd, gdd)
+
+
+def test_errors():
+    from vidar_amd.third_lib import dvr, dvxlr
+    sigma, origin, points, tindex = case("small_grid")
+    d = dev(sigma, origin, points, tindex)
+    with pytest.raises(RuntimeError):
+        dvxlr.render(d[0].cpu(), *d[1:])                 # CHECK_CUDA
+    with pytest.raises(RuntimeError):
+        dvxlr.render(d[0].transpose(3, 4), *d[1:])       # CHECK_CONTIGUOUS
+    with pytest.raises(ValueError):
+        dvr.render(*d, "huber")
+    with pytest.raises(ValueError):
+        dvr.render_forward(*d, [1, 4, 24, 20], "val")
+
+
+def test_full_size_properties():
+    """BASELINE-size ray set (30k rays, 16x200x200): properties that need no oracle."""
+    from vidar_amd.third_lib import dvxlr
+    from vidar_amd.synthetic import ray_set
+    sigma, origin, points, tindex = ray_set(seed=11, N=1, T=1, rays_per_frame=30000)
+    d = dev(sigma, origin, points, tindex)
+    pred, gt, dd, idx = dvxlr.render(*d)
+    hit = pred >= 0
+    assert hit.float().mean() > 0.9
+    live = (idx != 0).any(-1)
+    cnt = live.sum(-1)
+    assert int(cnt.max()) <= 420                     # ray cannot cross more voxels than X+Y+Z
+    # consecutive live samples are distinct voxels that differ by <=1 per axis (merged path)
+    step = (idx[..., 1:, :] - idx[..., :-1, :]).abs()
+    both = live[..., 1:] & live[..., :-1]
+    assert float(step[both].max()) <= 1.0 and bool((step[both].sum(-1) > 0).all())
+    assert bool((pred[hit] > 0).all()) and bool((pred[hit] < 500).all())
+    assert bool((dd <= 1e-6).all())                  # more density can only shorten the ray
+    # linearity of the scatter: get_grad_sigma(a*em) == a*get_grad_sigma(em)
+    em = dd * 0.5
+    g1 = dvxlr.get_grad_sigma(em, idx, d[3], d[0])[0]
+    g2 = dvxlr.get_grad_sigma(em * 2, idx, d[3], d[0])[0]
+    torch.testing.assert_close(g2, g1 * 2, rtol=1e-4, atol=1e-5)
+    assert abs(float(g1.sum()) - float(em.double().sum())) <= 1e-3 * float(em.double().abs().sum())

@@ -1,0 +1,57 @@
+"""CPU: numpy KNN restatement vs the reference's own knn_cpu.cpp build (oracle/_ref) + invariants
+from the reference's example.py (CD(x,x) = 0, bidirectional = fwd + bwd)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chamfer as C
+
+
+def clouds(seed, N, P1, P2, dup=False):
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-50, 50, (N, P1, 3)).astype(np.float32)
+    b = rng.uniform(-50, 50, (N, P2, 3)).astype(np.float32)
+    if dup and P2 >= 8:          # exact ties: duplicated target points -> lowest index must win
+        b[:, P2 // 2:P2 // 2 + 4] = b[:, :4]
+        a[:, :4] = b[:, :4]
+    return a, b
+
+
+@pytest.mark.parametrize("shape", [(1, 100, 50), (2, 257, 1031), (1, 1, 1), (3, 64, 7)])
+def test_knn_matches_reference_build(shape, ref_modules):
+    ref = ref_modules("ref_chamferdist_C")
+    N, P1, P2 = shape
+    a, b = clouds(0, N, P1, P2, dup=True)
+    l1 = np.array([P1 - (n % 2) * (P1 // 3) for n in range(N)], np.int64)
+    l2 = np.array([P2 - (n % 2) * (P2 // 4) for n in range(N)], np.int64)
+    ri, rd = ref.knn_points_idx(torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(l1),
+                                torch.from_numpy(l2), 1, -1)
+    oi, od = C.knn_points_idx(a, b, l1, l2)
+    assert np.array_equal(ri.numpy(), oi)
+    assert np.array_equal(rd.numpy(), od), "squared distances must be bit-exact"
+    g = np.random.default_rng(1).standard_normal(od.shape).astype(np.float32)
+    r1, r2 = ref.knn_points_backward(torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(l1),
+                                     torch.from_numpy(l2), ri, torch.from_numpy(g))
+    o1, o2 = C.knn_points_backward(a, b, l1, l2, oi, g)
+    np.testing.assert_allclose(r1.numpy(), o1, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(r2.numpy(), o2, rtol=1e-5, atol=1e-5)
+
+
+def test_knn_empty_target(ref_modules):
+    ref = ref_modules("ref_chamferdist_C")
+    a, b = clouds(2, 1, 10, 5)
+    l1 = np.array([10], np.int64); l2 = np.array([0], np.int64)
+    ri, rd = ref.knn_points_idx(torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(l1),
+                                torch.from_numpy(l2), 1, -1)
+    oi, od = C.knn_points_idx(a, b, l1, l2)
+    assert np.array_equal(ri.numpy(), oi) and np.array_equal(rd.numpy(), od)
+
+
+def test_invariants():
+    a, b = clouds(3, 1, 300, 200)
+    assert C.compute_chamfer_distance(a[0], a[0]) == 0.0
+    s, d, i1, i2 = C.chamfer_distance_mmdet3d(a, b)
+    _, d1 = C.knn_points_idx(a, b); _, d2 = C.knn_points_idx(b, a)
+    np.testing.assert_allclose(s, d1.mean(), rtol=1e-5)
+    np.testing.assert_allclose(d, d2.mean(), rtol=1e-5)
+    assert C.compute_chamfer_distance_inner(a[0] + 1000, b[0], (-51.2, -51.2, -5, 51.2, 51.2, 3)) == 0.0

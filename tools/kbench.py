@@ -1,0 +1,74 @@
+"""Per-kernel timing of the HIP ops at BASELINE sizes (HIP events on torch's current stream, which
+is the stream every op launches on).  Prints one JSON line per op: ms, algorithmic GB/s."""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def timeit(fn, warm=3, it=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+
+
+def report(name, ms, nbytes=None, **kw):
+    d = {"op": name, "ms": round(ms, 4)}
+    if nbytes:
+        d["alg_MB"] = round(nbytes / 1e6, 2); d["GBps"] = round(nbytes / ms / 1e6, 1)
+        d["frac_8TBps"] = round(nbytes / ms / 1e6 / 8000, 4)
+    d.update(kw)
+    print(json.dumps(d), flush=True)
+
+
+def bench_dvr(which):
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvr, dvxlr, dvxlr_v2
+    t = lambda a: torch.from_numpy(a).cuda()
+    for T, rpf in ((1, 30000), (5, 30000)):
+        sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=T, rays_per_frame=rpf))
+        N, M = tindex.shape
+        vol = sigma.numel() * 4
+        out = dvxlr.render(sigma, origin, points, tindex)
+        cnt = int(((out[3] != 0).any(-1)).sum())
+        ms = timeit(lambda: dvxlr.render(sigma, origin, points, tindex))
+        report(f"dvxlr.render T={T} M={M}", ms, vol + N * M * 16 + N * M * 4 * (2 + 1026 * 4), samples=cnt)
+        em = out[2] * 0.5
+        ms = timeit(lambda: dvxlr.get_grad_sigma(em, out[3], tindex, sigma))
+        report(f"dvxlr.get_grad_sigma T={T} M={M}", ms, N * M * 1026 * 16 + 2 * vol)
+        ms = timeit(lambda: dvr.render_forward(sigma, origin, points, tindex, [T, 16, 200, 200], "train"))
+        report(f"dvr.render_forward T={T} M={M}", ms, vol + N * M * 24 + cnt * 4)
+        ms = timeit(lambda: dvr.render(sigma, origin, points, tindex, "l1"))
+        report(f"dvr.render T={T} M={M}", ms, 2 * vol + N * M * 24 + cnt * 12)
+        ms = timeit(lambda: dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma))
+        report(f"dvxlr_v2.render_v2 T={T} M={M}", ms, 2 * vol + N * M * 16 + N * M * 4 * (2 + 1026 * 6))
+        del out, em
+
+
+def bench_knn(which):
+    from vidar_amd.third_lib.chamferdist import knn_points
+    rng = np.random.default_rng(0)
+    for P1, P2 in ((30000, 30000), (10000, 30000), (30000, 10000)):
+        a = torch.from_numpy(rng.uniform(-50, 50, (1, P1, 3)).astype(np.float32)).cuda()
+        b = torch.from_numpy(rng.uniform(-50, 50, (1, P2, 3)).astype(np.float32)).cuda()
+        ms = timeit(lambda: knn_points(a, b))
+        report(f"knn1_d3 {P1}x{P2}", ms, 12 * (P1 + P2) + 12 * P1, Gpairs_s=round(P1 * P2 / ms / 1e6, 1),
+               fp32_TFLOPs=round(P1 * P2 * 8 / ms / 1e9, 2))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["dvr", "knn"]
+    print(json.dumps({"device": torch.cuda.get_device_name(0)}))
+    for w in which:
+        globals()["bench_" + w](w)

@@ -1,0 +1,156 @@
+// Brute-force nearest neighbour (K = 1, D = 3) for the chamfer distance, gfx950.
+//
+// Replaces (behaviour) third_lib/chamfer_dist/chamferdist/chamferdist/knn.cu:190-235 (V3 kernel,
+// the variant ChooseVersion picks for D=3,K=1, knn.cu:266-269), host :297-435, backward :443-544,
+// and the CPU path knn_cpu.cpp:7-58, :64-106 whose arithmetic we follow bit-for-bit:
+//   dist = ((dx*dx + dy*dy) + dz*dz) in fp32 with NO fused multiply-add (compiled with
+//   -ffp-contract=off), ties resolved to the lowest p2 index (strict '<', knn_cpu.cpp:41).
+//
+// Design: FP32-VALU bound (P1*P2 pair evaluations), not HBM bound.
+//  * every lane owns R query points in registers; the p2 point of the iteration is wave-uniform
+//    and comes in through the scalar unit (s_load), so a pair costs only VALU work;
+//  * P2 is split into chunks across blockIdx.y so that even one 10k-point cloud fills 256 CUs;
+//    chunk winners meet in a 64-bit atomicMin on (dist_bits << 32 | index): for non-negative
+//    floats the bit pattern is order preserving, and the low word makes the lowest index win ties
+//    exactly like the sequential scan of the reference;
+//  * a finalize kernel unpacks the keys into the int64 idx / fp32 dist tensors of the API.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vidar_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kR = 4;  // query points per lane
+
+__global__ __launch_bounds__(kThreads) void knn1_d3_scan_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2, const int64_t* __restrict__ len1,
+    const int64_t* __restrict__ len2, unsigned long long* __restrict__ keys, int P1, int P2,
+    int chunk) {
+  const int n = blockIdx.z;
+  const int l1 = (int)min((int64_t)P1, len1[n]);
+  const int l2 = (int)min((int64_t)P2, len2[n]);
+  const int j0 = blockIdx.y * chunk;
+  const int j1 = min(j0 + chunk, l2);
+  const int ibase = blockIdx.x * (kThreads * kR) + threadIdx.x;
+  if (j0 >= j1 || blockIdx.x * (kThreads * kR) >= l1) return;
+
+  float px[kR], py[kR], pz[kR], best[kR];
+  int bidx[kR];
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int i = min(ibase + r * kThreads, P1 - 1);
+    const float* p = p1 + ((size_t)n * P1 + i) * 3;
+    px[r] = p[0]; py[r] = p[1]; pz[r] = p[2];
+    best[r] = __builtin_inff();
+    bidx[r] = -1;
+  }
+  const float* q = p2 + (size_t)n * P2 * 3;
+#pragma unroll 4
+  for (int j = j0; j < j1; ++j) {
+    const float qx = q[3 * j + 0], qy = q[3 * j + 1], qz = q[3 * j + 2];  // wave-uniform -> s_load
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const float dx = px[r] - qx, dy = py[r] - qy, dz = pz[r] - qz;
+      float d = dx * dx;
+      d = d + dy * dy;
+      d = d + dz * dz;
+      const bool better = d < best[r];
+      best[r] = better ? d : best[r];
+      bidx[r] = better ? j : bidx[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kR; ++r) {
+    const int i = ibase + r * kThreads;
+    if (i < l1 && bidx[r] >= 0) {
+      const unsigned long long key =
+          ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)bidx[r];
+      atomicMin(keys + (size_t)n * P1 + i, key);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void knn1_finalize_kernel(
+    const unsigned long long* __restrict__ keys, const int64_t* __restrict__ len1,
+    const int64_t* __restrict__ len2, int64_t* __restrict__ idx, float* __restrict__ dist, int P1) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P1) return;
+  const unsigned long long k = keys[(size_t)n * P1 + i];
+  // rows beyond lengths1 and empty targets keep the reference's zero fill (knn_cpu.cpp:18-19)
+  const bool live = (i < len1[n]) && (len2[n] > 0) && (k != ~0ull);
+  idx[(size_t)n * P1 + i] = live ? (int64_t)(k & 0xffffffffull) : 0;
+  dist[(size_t)n * P1 + i] = live ? __uint_as_float((unsigned)(k >> 32)) : 0.f;
+}
+
+// grad_p1[n,i,:] = 2 g (p1 - p2[idx]);  grad_p2[n,idx,:] -= the same (knn_cpu.cpp:93-101)
+__global__ __launch_bounds__(256) void knn1_d3_bwd_kernel(
+    const float* __restrict__ p1, const float* __restrict__ p2, const int64_t* __restrict__ len1,
+    const int64_t* __restrict__ len2, const int64_t* __restrict__ idx,
+    const float* __restrict__ grad_dist, float* __restrict__ grad_p1, float* __restrict__ grad_p2,
+    int P1, int P2) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P1) return;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (i < len1[n] && len2[n] > 0) {
+    const int64_t j = idx[(size_t)n * P1 + i];
+    const float g2 = 2.0f * grad_dist[(size_t)n * P1 + i];
+    const float* a = p1 + ((size_t)n * P1 + i) * 3;
+    const float* b = p2 + ((size_t)n * P2 + j) * 3;
+    gx = g2 * (a[0] - b[0]); gy = g2 * (a[1] - b[1]); gz = g2 * (a[2] - b[2]);
+    float* o = grad_p2 + ((size_t)n * P2 + j) * 3;
+    unsafeAtomicAdd(o + 0, -gx); unsafeAtomicAdd(o + 1, -gy); unsafeAtomicAdd(o + 2, -gz);
+  }
+  float* o1 = grad_p1 + ((size_t)n * P1 + i) * 3;
+  o1[0] = gx; o1[1] = gy; o1[2] = gz;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vidar_knn1_d3_workspace_bytes(int N, int P1) { return sizeof(unsigned long long) * (size_t)N * P1; }
+
+int vidar_knn1_d3_fwd(const float* p1, const float* p2, const int64_t* lengths1,
+                      const int64_t* lengths2, int64_t* idx, float* dist2, void* workspace, int N,
+                      int P1, int P2, void* stream) {
+  if (N < 0 || P1 < 0 || P2 < 0) return VIDAR_ERR_BAD_ARG;
+  if (N == 0 || P1 == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long* keys = (unsigned long long*)workspace;
+  hipError_t e = hipMemsetAsync(keys, 0xff, sizeof(unsigned long long) * (size_t)N * P1, s);
+  if (e != hipSuccess) return (int)e;
+  if (P2 > 0) {
+    const int bx = (P1 + kThreads * kR - 1) / (kThreads * kR);
+    int S = (2048 + bx * N - 1) / (bx * N);
+    const int maxS = (P2 + 127) / 128;
+    S = S < 1 ? 1 : (S > maxS ? maxS : S);
+    const int chunk = (P2 + S - 1) / S;
+    S = (P2 + chunk - 1) / chunk;
+    hipLaunchKernelGGL(knn1_d3_scan_kernel, dim3(bx, S, N), dim3(kThreads), 0, s, p1, p2, lengths1,
+                       lengths2, keys, P1, P2, chunk);
+  }
+  hipLaunchKernelGGL(knn1_finalize_kernel, dim3((P1 + 255) / 256, N), dim3(256), 0, s, keys,
+                     lengths1, lengths2, idx, dist2, P1);
+  return (int)hipGetLastError();
+}
+
+int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
+                      const int64_t* lengths2, const int64_t* idx, const float* grad_dist2,
+                      float* grad_p1, float* grad_p2, int N, int P1, int P2, void* stream) {
+  if (N < 0 || P1 < 0 || P2 < 0) return VIDAR_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (N > 0 && P2 > 0) {
+    hipError_t e = hipMemsetAsync(grad_p2, 0, sizeof(float) * (size_t)N * P2 * 3, s);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (N == 0 || P1 == 0) return 0;
+  hipLaunchKernelGGL(knn1_d3_bwd_kernel, dim3((P1 + 255) / 256, N), dim3(256), 0, s, p1, p2,
+                     lengths1, lengths2, idx, grad_dist2, grad_p1, grad_p2, P1, P2);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+"""`chamferdist._C` -- same callables as the reference's pybind module
+(third_lib/chamfer_dist/chamferdist/chamferdist/ext.cpp:5-11).  The hot case K=1, D=3 runs the
+gfx950 HIP kernel behind vidar_knn1_d3_{fwd,bwd}; other (D, K) are not on ViDAR's path
+(every call site uses K=1 on xyz clouds: chamfer.py:77-93) and raise NotImplementedError."""
+from __future__ import annotations
+
+import torch
+
+from ..._lib import lib, check, ptr, stream_of
+
+
+def knn_check_version(version: int, D: int, K: int) -> bool:
+    """knn.cu:237-253 semantics restricted to the one implementation we ship."""
+    return version in (-1, 3) and D == 3 and K == 1
+
+
+def _prep(p1, p2, lengths1, lengths2):
+    if not (p1.is_cuda and p2.is_cuda):
+        raise RuntimeError("p1/p2 must be CUDA tensors (vidar_amd has no CPU path)")
+    if p1.dtype != torch.float32 or p2.dtype != torch.float32:
+        raise RuntimeError("p1/p2 must be float32")
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != 3 or p2.shape[2] != 3:
+        raise NotImplementedError("only D == 3 point clouds are supported")
+    if p1.shape[0] != p2.shape[0]:
+        raise RuntimeError("batch sizes differ")
+    return (p1.contiguous(), p2.contiguous(), lengths1.to(torch.int64).contiguous(),
+            lengths2.to(torch.int64).contiguous())
+
+
+def knn_points_idx(p1, p2, lengths1, lengths2, K: int = 1, version: int = -1):
+    """-> (idx int64 [N,P1,K], dists f32 [N,P1,K]) ; squared L2, ties -> lowest index."""
+    if K != 1:
+        raise NotImplementedError("only K == 1 is supported")
+    p1, p2, l1, l2 = _prep(p1, p2, lengths1, lengths2)
+    N, P1, _ = p1.shape
+    P2 = p2.shape[1]
+    idx = torch.empty((N, P1, 1), dtype=torch.int64, device=p1.device)
+    dist = torch.empty((N, P1, 1), dtype=torch.float32, device=p1.device)
+    ws = torch.empty((max(N * P1, 1),), dtype=torch.int64, device=p1.device)
+    check(lib().vidar_knn1_d3_fwd(ptr(p1), ptr(p2), ptr(l1), ptr(l2), ptr(idx), ptr(dist), ptr(ws),
+                                  N, P1, P2, stream_of(p1)), "knn_points_idx")
+    return idx, dist
+
+
+def knn_points_backward(p1, p2, lengths1, lengths2, idxs, grad_dists):
+    """-> (grad_p1 [N,P1,3], grad_p2 [N,P2,3])   (knn_cpu.cpp:64-106)"""
+    if idxs.shape[-1] != 1:
+        raise NotImplementedError("only K == 1 is supported")
+    p1, p2, l1, l2 = _prep(p1, p2, lengths1, lengths2)
+    N, P1, _ = p1.shape
+    P2 = p2.shape[1]
+    g1 = torch.empty_like(p1)
+    g2 = torch.empty_like(p2)
+    check(lib().vidar_knn1_d3_bwd(ptr(p1), ptr(p2), ptr(l1), ptr(l2), ptr(idxs.contiguous()),
+                                  ptr(grad_dists.contiguous().float()), ptr(g1), ptr(g2), N, P1, P2,
+                                  stream_of(p1)), "knn_points_backward")
+    return g1, g2
