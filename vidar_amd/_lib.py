@@ -18,6 +18,9 @@ class VidarHipError(RuntimeError):
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so.7; it must be the copy already loaded when our
+        # library is dlopen'ed, otherwise two HIP runtimes fight over the device (hipErrorNoDevice).
+        import torch  # noqa: F401
         if not LIB_PATH.exists():
             raise VidarHipError(
                 f"{LIB_PATH} not found: build it with `python -m vidar_amd.build` "

@@ -28,6 +28,7 @@
 #include <math.h>
 
 #include "vidar_hip.h"
+#include "vidar_common.h"
 
 namespace {
 
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(256) void dvr_init_kernel(const float* __restrict__
     occupancy[((((size_t)n * g.T + ts) * g.Z + vz) * g.Y + vy) * g.X + vx] = 1.f;
 }
 
-inline int hip_ret() { return (int)hipGetLastError(); }
+inline int hip_ret() { return vidar_last_error(); }
 inline bool bad_dims(int N, int M, int T, int Z, int Y, int X) {
   return N < 0 || M < 0 || T <= 0 || Z <= 0 || Y <= 0 || X <= 0;
 }
@@ -433,6 +434,7 @@ int vidar_dvxlr_max_d(void) { return kDvxlrMaxD; }
 int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,
                                  const float* tindex, float* pred_dist, float* gt_dist, int N, int M,
                                  int T, int TO, int Z, int Y, int X, int train_phase, void* stream) {
+  VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || TO <= 0 || (train_phase != 0 && train_phase != 1))
     return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
@@ -440,13 +442,14 @@ int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const 
   dim3 grid((M + kWave - 1) / kWave, N);
   hipLaunchKernelGGL(dvr_render_forward_kernel, grid, dim3(kWave), 0, (hipStream_t)stream, sigma,
                      origin, points, tindex, pred_dist, gt_dist, M, g, train_phase);
-  return hip_ret();
+  return vidar_last_error();
 }
 
 int vidar_dvr_render_f32(const float* sigma, const float* origin, const float* points,
                          const float* tindex, float* pred_dist, float* gt_dist, float* grad_sigma,
                          int N, int M, int T, int TO, int Z, int Y, int X, int loss_type,
                          void* stream) {
+  VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || TO <= 0 || loss_type < 0 || loss_type > 2)
     return VIDAR_ERR_BAD_ARG;
   hipError_t e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * (size_t)N * T * Z * Y * X,
@@ -457,11 +460,12 @@ int vidar_dvr_render_f32(const float* sigma, const float* origin, const float* p
   dim3 grid((M + kWave - 1) / kWave, N);
   hipLaunchKernelGGL(dvr_render_kernel, grid, dim3(kWave), 0, (hipStream_t)stream, sigma, origin,
                      points, tindex, pred_dist, gt_dist, grad_sigma, M, g, loss_type);
-  return hip_ret();
+  return vidar_last_error();
 }
 
 int vidar_dvr_init_f32(const float* points, const float* tindex, float* occupancy, int N, int M,
                        int T, int Z, int Y, int X, void* stream) {
+  VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X)) return VIDAR_ERR_BAD_ARG;
   hipError_t e = hipMemsetAsync(occupancy, 0, sizeof(float) * (size_t)N * T * Z * Y * X,
                                 (hipStream_t)stream);
@@ -471,13 +475,14 @@ int vidar_dvr_init_f32(const float* points, const float* tindex, float* occupanc
   dim3 grid((M + 255) / 256, N);
   hipLaunchKernelGGL(dvr_init_kernel, grid, dim3(256), 0, (hipStream_t)stream, points, tindex,
                      occupancy, M, g);
-  return hip_ret();
+  return vidar_last_error();
 }
 
 int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float* points,
                            const float* tindex, float* pred_dist, float* gt_dist, float* dd_dsigma,
                            float* indices, int N, int M, int T, int TO, int Z, int Y, int X,
                            void* stream) {
+  VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || TO <= 0) return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
@@ -485,7 +490,7 @@ int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float*
   hipLaunchKernelGGL(dvxlr_render_kernel<false>, grid, dim3(kWave), 0, (hipStream_t)stream, sigma,
                      (const float*)nullptr, origin, points, tindex, pred_dist, gt_dist, dd_dsigma,
                      indices, (float*)nullptr, (float*)nullptr, M, g);
-  return hip_ret();
+  return vidar_last_error();
 }
 
 int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float* points,
@@ -493,6 +498,7 @@ int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float
                             float* gt_dist, float* dd_dsigma, float* indices, float* ray_pred,
                             float* indicator, int N, int M, int T, int TO, int Z, int Y, int X,
                             void* stream) {
+  VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || TO <= 0) return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
@@ -500,12 +506,13 @@ int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float
   hipLaunchKernelGGL(dvxlr_render_kernel<true>, grid, dim3(kWave), 0, (hipStream_t)stream, sigma,
                      sigma_regul, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices,
                      ray_pred, indicator, M, g);
-  return hip_ret();
+  return vidar_last_error();
 }
 
 int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult, const float* indices,
                                    const float* tindex, float* grad_sigma, int N, int M, int L, int T,
                                    int Z, int Y, int X, void* stream) {
+  VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || L < 0) return VIDAR_ERR_BAD_ARG;
   hipError_t e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * (size_t)N * T * Z * Y * X,
                                 (hipStream_t)stream);
@@ -516,7 +523,7 @@ int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult, const float* i
   hipLaunchKernelGGL(dvxlr_scatter_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                      elementwise_mult, indices, tindex, (const float*)nullptr, (const float*)nullptr,
                      grad_sigma, (float*)nullptr, M, L, g);
-  return hip_ret();
+  return vidar_last_error();
 }
 
 int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* indices,
@@ -524,6 +531,7 @@ int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* 
                                     const float* grad_ray_pred, float* grad_sigma,
                                     float* grad_sigma_regul, int N, int M, int L, int T, int Z, int Y,
                                     int X, void* stream) {
+  VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || L < 0) return VIDAR_ERR_BAD_ARG;
   const size_t bytes = sizeof(float) * (size_t)N * T * Z * Y * X;
   hipError_t e = hipMemsetAsync(grad_sigma, 0, bytes, (hipStream_t)stream);
@@ -536,7 +544,7 @@ int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* 
   hipLaunchKernelGGL(dvxlr_scatter_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
                      elementwise_mult, indices, tindex, indicator, grad_ray_pred, grad_sigma,
                      grad_sigma_regul, M, L, g);
-  return hip_ret();
+  return vidar_last_error();
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "vidar_hip.h"
+#include "vidar_common.h"
 
 namespace {
 
@@ -117,6 +118,7 @@ size_t vidar_knn1_d3_workspace_bytes(int N, int P1) { return sizeof(unsigned lon
 int vidar_knn1_d3_fwd(const float* p1, const float* p2, const int64_t* lengths1,
                       const int64_t* lengths2, int64_t* idx, float* dist2, void* workspace, int N,
                       int P1, int P2, void* stream) {
+  VIDAR_ENTER();
   if (N < 0 || P1 < 0 || P2 < 0) return VIDAR_ERR_BAD_ARG;
   if (N == 0 || P1 == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -135,12 +137,13 @@ int vidar_knn1_d3_fwd(const float* p1, const float* p2, const int64_t* lengths1,
   }
   hipLaunchKernelGGL(knn1_finalize_kernel, dim3((P1 + 255) / 256, N), dim3(256), 0, s, keys,
                      lengths1, lengths2, idx, dist2, P1);
-  return (int)hipGetLastError();
+  return vidar_last_error();
 }
 
 int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
                       const int64_t* lengths2, const int64_t* idx, const float* grad_dist2,
                       float* grad_p1, float* grad_p2, int N, int P1, int P2, void* stream) {
+  VIDAR_ENTER();
   if (N < 0 || P1 < 0 || P2 < 0) return VIDAR_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (N > 0 && P2 > 0) {
@@ -150,7 +153,7 @@ int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
   if (N == 0 || P1 == 0) return 0;
   hipLaunchKernelGGL(knn1_d3_bwd_kernel, dim3((P1 + 255) / 256, N), dim3(256), 0, s, p1, p2,
                      lengths1, lengths2, idx, grad_dist2, grad_p1, grad_p2, P1, P2);
-  return (int)hipGetLastError();
+  return vidar_last_error();
 }
 
 }  // extern "C"
