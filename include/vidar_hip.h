@@ -111,6 +111,49 @@ int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
                       const int64_t* lengths2, const int64_t* idx, const float* grad_dist2,
                       float* grad_p1, float* grad_p2, int N, int P1, int P2, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Multi-scale deformable attention.  Replaces mmcv._ext.ms_deform_attn_{forward,backward}
+ * (mmcv-full 1.4.0, third party) as called from
+ * projects/mmdet3d_plugin/bevformer/modules/multi_scale_deformable_attn_function.py:118-124, :150-160.
+ *   value [B,Nv,H,C] f32 (C must be 32), spatial_shapes [L,2] i64 (h,w), level_start_index [L] i64,
+ *   sampling_loc [B,Nq,H,L,P,2] f32 in [0,1] (x,y), attn_weight [B,Nq,H,L,P] f32, out [B,Nq,H*C].
+ * im2col_step of the reference API has no meaning here and is dropped at the Python layer.
+ * bwd: grad_value is zeroed by the call then accumulated with fp32 atomics; grad_sampling_loc and
+ * grad_attn_weight are fully written (the reference expects pre-zeroed buffers, function.py:146-148).
+ * ------------------------------------------------------------------------- */
+int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* sampling_loc,
+                       const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq,
+                       int L, int P, void* stream);
+int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* sampling_loc,
+                       const float* attn_weight, const float* grad_out, float* grad_value,
+                       float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
+                       int Nq, int L, int P, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * LatentRendering ray-march (fused).  Replaces the torch op chain of
+ * projects/mmdet3d_plugin/bevformer/modules/ray_operations/latent_rendering.py:96-150.
+ * All maps are channel-last [bs, H*W, Z] f32 with Z == 16 (pred_height == embed_dims/reduction).
+ * step = grid_step / (min(H,W)//2) rounded to f32 (:102-104); act: 0 = 'sigmoid', 1 = 'exp' (:117-123).
+ *   prob   : occ logits -> path_prob = prod_{k<G,valid}(1 - act(occ(n_k))) * act(occ(n_cell))   (:96-129)
+ *   gather : feat = sum_k a(n_k) m_k / (sum_k m_k + eps), m_k = path_prob(n_k)*valid2_k          (:131-150)
+ * Backward entry points zero their gradient outputs and accumulate with fp32 atomics.
+ * ------------------------------------------------------------------------- */
+int vidar_latent_render_prob_fwd_f32(const float* occ, float* path_prob, int bs, int H, int W, int Z,
+                                     int grid_num, float step, int act, void* stream);
+int vidar_latent_render_prob_bwd_f32(const float* occ, const float* grad_path_prob, float* grad_occ,
+                                     int bs, int H, int W, int Z, int grid_num, float step, int act,
+                                     void* stream);
+int vidar_latent_render_gather_fwd_f32(const float* path_prob, const float* lora_a, float* feat,
+                                       float* msum, int bs, int H, int W, int Z, int grid_num,
+                                       float step, float eps, void* stream);
+int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora_a, const float* feat,
+                                       const float* msum, const float* grad_feat,
+                                       float* grad_path_prob, float* grad_lora_a, int bs, int H,
+                                       int W, int Z, int grid_num, float step, float eps,
+                                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

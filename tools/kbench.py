@@ -67,8 +67,46 @@ def bench_knn(which):
                fp32_TFLOPs=round(P1 * P2 * 8 / ms / 1e9, 2))
 
 
+def bench_msda(which):
+    from oracle import msda as M   # operand generator only (bench tool, not product)
+    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_forward, _msda_backward
+    fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
+    for name, B, shapes, Nq, P in (("TSA", 2, [(200, 200)], 40000, 4), ("SCA", 6, fpn, 10000, 8),
+                                   ("Pred", 1, [(200, 200)], 40000, 4)):
+        value, sh, loc, w = M.make_case(0, B, shapes, Nq, P=P)
+        value, sh, loc, w = value.cuda(), sh.cuda(), loc.cuda(), w.cuda()
+        lsi = M.level_start_index(shapes).cuda()
+        L = len(shapes); Nv = value.shape[1]
+        fwd_bytes = 4 * (B * Nv * 256 + B * Nq * 8 * L * P * 3 + B * Nq * 256)
+        ms = timeit(lambda: _msda_forward(value, sh, lsi, loc, w))
+        report(f"msda_fwd {name}", ms, fwd_bytes)
+        go = torch.randn(B, Nq, 256, device="cuda")
+        ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go))
+        report(f"msda_bwd {name}", ms, fwd_bytes + 4 * (B * Nq * 256 + B * Nv * 256 + B * Nq * 8 * L * P * 3))
+
+
+def bench_lr(which):
+    from vidar_amd.plugin.modules.ray_operations.latent_rendering import _PathProb, _RayGather
+    for step in (1.0, 0.5):
+        occ = torch.randn(1, 200, 200, 16, device="cuda", requires_grad=True)
+        a = torch.randn(1, 200, 200, 16, device="cuda", requires_grad=True)
+        Q = 40000
+        ms = timeit(lambda: _PathProb.apply(occ, 256, step, 0))
+        report(f"lr_prob_fwd step={step}", ms, 4 * Q * 32)
+        p = _PathProb.apply(occ, 256, step, 0)
+        g = torch.randn_like(p)
+        ms = timeit(lambda: torch.autograd.grad(p, occ, g, retain_graph=True))
+        report(f"lr_prob_bwd step={step}", ms, 4 * Q * 48)
+        pd = p.detach().requires_grad_(True)
+        ms = timeit(lambda: _RayGather.apply(pd, a, 256, step, 1e-3))
+        report(f"lr_gather_fwd step={step}", ms, 4 * Q * 64)
+        f = _RayGather.apply(pd, a, 256, step, 1e-3)
+        ms = timeit(lambda: torch.autograd.grad(f, [pd, a], g, retain_graph=True))
+        report(f"lr_gather_bwd step={step}", ms, 4 * Q * 112)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["dvr", "knn"]
+    which = sys.argv[1:] or ["dvr", "knn", "msda", "lr"]
     print(json.dumps({"device": torch.cuda.get_device_name(0)}))
     for w in which:
         globals()["bench_" + w](w)

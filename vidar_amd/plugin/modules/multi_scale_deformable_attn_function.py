@@ -1,0 +1,77 @@
+"""MultiScaleDeformableAttnFunction_fp32 / _fp16 -- same autograd surface as
+projects/mmdet3d_plugin/bevformer/modules/multi_scale_deformable_attn_function.py:15-163,
+backed by vidar_msda_{fwd,bwd}_f32 (gfx950 HIP) instead of mmcv._ext."""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ..._lib import lib, check, ptr, stream_of
+
+
+def _msda_forward(value, shapes, lsi, loc, w):
+    B, Nv, H, C = value.shape
+    _, Nq, H2, L, P, two = loc.shape
+    if H2 != H or two != 2 or w.shape != (B, Nq, H, L, P):
+        raise RuntimeError("inconsistent MSDA operand shapes")
+    out = torch.empty((B, Nq, H * C), dtype=torch.float32, device=value.device)
+    check(lib().vidar_msda_fwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w), ptr(out),
+                                   B, Nv, H, C, Nq, L, P, stream_of(value)), "ms_deform_attn_forward")
+    return out
+
+
+def _msda_backward(value, shapes, lsi, loc, w, grad_out):
+    B, Nv, H, C = value.shape
+    _, Nq, _, L, P, _ = loc.shape
+    gv = torch.empty_like(value)
+    gl = torch.empty_like(loc)
+    gw = torch.empty_like(w)
+    check(lib().vidar_msda_bwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w), ptr(grad_out),
+                                   ptr(gv), ptr(gl), ptr(gw), B, Nv, H, C, Nq, L, P,
+                                   stream_of(value)), "ms_deform_attn_backward")
+    return gv, gl, gw
+
+
+def _prep(value, shapes, lsi, loc, w):
+    if not value.is_cuda:
+        raise RuntimeError("MultiScaleDeformableAttnFunction needs CUDA tensors (no CPU fallback)")
+    f = lambda t: t.float().contiguous()
+    i = lambda t: t.to(device=value.device, dtype=torch.int64).contiguous()
+    return f(value), i(shapes), i(lsi), f(loc), f(w)
+
+
+class MultiScaleDeformableAttnFunction_fp32(Function):
+    """apply(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+    attention_weights, im2col_step) -> [B, Nq, H*C]; inputs are cast to fp32 like the reference's
+    custom_fwd(cast_inputs=torch.float32) (function.py:92)."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step          # accepted, unused
+        ctx.in_dtypes = (value.dtype, sampling_locations.dtype, attention_weights.dtype)
+        v, s, l, loc, w = _prep(value, value_spatial_shapes, value_level_start_index,
+                                sampling_locations, attention_weights)
+        out = _msda_forward(v, s, l, loc, w)
+        ctx.save_for_backward(v, s, l, loc, w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        v, s, l, loc, w = ctx.saved_tensors
+        gv, gl, gw = _msda_backward(v, s, l, loc, w, grad_output.float().contiguous())
+        dv, dl, dw = ctx.in_dtypes
+        return gv.to(dv), None, None, gl.to(dl), gw.to(dw), None
+
+
+# the reference's fp16 variant differs only in the autocast decorator (function.py:15-87)
+MultiScaleDeformableAttnFunction_fp16 = MultiScaleDeformableAttnFunction_fp32
+
+
+def multi_scale_deformable_attn(value, spatial_shapes, level_start_index, sampling_locations,
+                                attention_weights, im2col_step=64):
+    return MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
+                                                       sampling_locations, attention_weights,
+                                                       im2col_step)
