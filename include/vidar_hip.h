@@ -154,6 +154,40 @@ int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora
                                        int W, int Z, int grid_num, float step, float eps,
                                        void* stream);
 
+/* ---------------------------------------------------------------------------
+ * ViDAR head ray-march over the predicted occupancy volume (fused).  Replaces the torch op chains
+ * of projects/mmdet3d_plugin/bevformer/dense_heads/vidar_head_base.py:
+ *   ray_ce     _get_grid_features :420-509 + cross_entropy(label 0) :586-592
+ *   ray_gumbel dense rays :594-630 + _custom_gumbel_softmax_distance :754-773
+ *   ray_argmax get_point_cloud_prediction :697-731 (test-time decode)
+ * sigma [F,Z,Y,X] f32 logits; origin [F,3]; pts [R,3] ray end points; tindex [R] f32 frame slot
+ * (<0 / NaN / >=F: ray skipped); all in voxel units.  K must be 512 (ray_grid_num of the released
+ * configs); step = ray_grid_step.  Outputs are per ray; reductions stay in the host framework.
+ *   ce[r]   = logsumexp_k(logit_k) - logit_0 over {end point, K waypoints}; valid[r] = 1 iff the
+ *             end point lies strictly inside the volume (others are dropped, :464-467); lse saved.
+ *   dist[r] = ((1-pn)+pn) * pd, pd = length of argmax_k(logit_k + noise[r,k]),
+ *             pn = softmax mass of waypoints farther than pd;  aux[r] = {pd, pn, lse}.
+ * Backward entry points zero grad_sigma and accumulate with fp32 atomics.
+ * ------------------------------------------------------------------------- */
+int vidar_ray_ce_fwd_f32(const float* sigma, const float* origin, const float* gt_pts,
+                         const float* tindex, float* ce, float* lse, float* valid, int F, int R,
+                         int Z, int Y, int X, int K, float step, void* stream);
+int vidar_ray_ce_bwd_f32(const float* sigma, const float* origin, const float* gt_pts,
+                         const float* tindex, const float* lse, const float* grad_ce,
+                         float* grad_sigma, int F, int R, int Z, int Y, int X, int K, float step,
+                         void* stream);
+int vidar_ray_gumbel_fwd_f32(const float* sigma, const float* origin, const float* pts,
+                             const float* tindex, const float* noise /*[R,K]*/, float* dist,
+                             float* aux /*[R,3]*/, int F, int R, int Z, int Y, int X, int K,
+                             float step, void* stream);
+int vidar_ray_gumbel_bwd_f32(const float* sigma, const float* origin, const float* pts,
+                             const float* tindex, const float* aux, const float* grad_dist,
+                             float* grad_sigma, int F, int R, int Z, int Y, int X, int K, float step,
+                             void* stream);
+int vidar_ray_argmax_f32(const float* sigma, const float* origin, const float* pts,
+                         const float* tindex, float* pred_dist, float* gt_dist, int F, int R, int Z,
+                         int Y, int X, int K, float step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
