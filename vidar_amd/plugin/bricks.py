@@ -1,0 +1,116 @@
+"""Small third-party building blocks the reference takes from mmcv / mmdet / torchvision, restated
+from their documented behaviour (none of them is vendored in the reference,
+so their parity is 'unpinned').  Parameter names follow the originals so released checkpoints map:
+  FFN.layers.{0.0,1}.*  (mmcv.cnn.bricks.transformer.FFN)
+  LearnedPositionalEncoding.{row_embed,col_embed}.weight  (mmdet)"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import FEEDFORWARD_NETWORK, POSITIONAL_ENCODING
+
+
+def xavier_init(module, gain=1, bias=0, distribution="normal"):
+    for m in ([module] if not isinstance(module, nn.Sequential) else module):
+        if hasattr(m, "weight") and m.weight is not None and m.weight.dim() > 1:
+            (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(m.weight, gain=gain)
+        if hasattr(m, "bias") and m.bias is not None:
+            nn.init.constant_(m.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    if hasattr(module, "weight") and module.weight is not None:
+        nn.init.constant_(module.weight, val)
+    if hasattr(module, "bias") and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def build_norm_layer(cfg, num_features):
+    typ = cfg.get("type", "LN")
+    if typ != "LN":
+        raise NotImplementedError(f"norm type {typ}")
+    return "ln", nn.LayerNorm(num_features, eps=cfg.get("eps", 1e-5))
+
+
+def build_activation(cfg):
+    typ = cfg.get("type", "ReLU")
+    if typ == "ReLU":
+        return nn.ReLU(inplace=cfg.get("inplace", False))
+    if typ == "GELU":
+        return nn.GELU()
+    raise NotImplementedError(typ)
+
+
+@FEEDFORWARD_NETWORK.register_module()
+class FFN(nn.Module):
+    """Linear -> act -> drop -> Linear -> drop, plus identity (x when none is given)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type="ReLU", inplace=True), ffn_drop=0., dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__()
+        assert num_fcs >= 2
+        self.embed_dims = embed_dims
+        layers, in_ch = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(in_ch, feedforward_channels), build_activation(act_cfg),
+                                        nn.Dropout(ffn_drop)))
+            in_ch = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = nn.Sequential(*layers)
+        self.dropout_layer = nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        return (x if identity is None else identity) + self.dropout_layer(out)
+
+
+@POSITIONAL_ENCODING.register_module()
+class LearnedPositionalEncoding(nn.Module):
+    """pos[b, :, y, x] = cat(col_embed[x], row_embed[y])  -> [bs, 2*num_feats, h, w]"""
+
+    def __init__(self, num_feats, row_num_embed=50, col_num_embed=50, init_cfg=None):
+        super().__init__()
+        self.row_embed = nn.Embedding(row_num_embed, num_feats)
+        self.col_embed = nn.Embedding(col_num_embed, num_feats)
+        self.num_feats = num_feats
+        nn.init.uniform_(self.row_embed.weight)
+        nn.init.uniform_(self.col_embed.weight)
+
+    def forward(self, mask):
+        h, w = mask.shape[-2:]
+        x_embed = self.col_embed(torch.arange(w, device=mask.device))
+        y_embed = self.row_embed(torch.arange(h, device=mask.device))
+        pos = torch.cat((x_embed.unsqueeze(0).repeat(h, 1, 1), y_embed.unsqueeze(1).repeat(1, w, 1)), -1)
+        return pos.permute(2, 0, 1).unsqueeze(0).repeat(mask.shape[0], 1, 1, 1)
+
+
+def rotate_nearest(img, angle_deg, center):
+    """torchvision.transforms.functional.rotate(img[C,H,W], angle, center=center) with its defaults
+    (nearest interpolation, zero fill, no expand), as used to align prev_bev
+    (modules/transformer.py:139-151).  [3P, recalled: inverse affine about `center`, angle
+    counter-clockwise, sampling grid at pixel centres, grid_sample(align_corners=False)]."""
+    C, H, W = img.shape
+    cx, cy = center[0] - W * 0.5, center[1] - H * 0.5
+    rot = math.radians(-float(angle_deg))
+    c, s = math.cos(rot), math.sin(rot)
+    m = [c, s, 0.0, -s, c, 0.0]
+    m[2] += m[0] * (-cx) + m[1] * (-cy) + cx
+    m[5] += m[3] * (-cx) + m[4] * (-cy) + cy
+    theta = img.new_tensor(m, dtype=torch.float32).view(2, 3)
+    xs = torch.linspace(-W * 0.5 + 0.5, W * 0.5 - 0.5, W, device=img.device)
+    ys = torch.linspace(-H * 0.5 + 0.5, H * 0.5 - 0.5, H, device=img.device)
+    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+    base = torch.stack((gx, gy, torch.ones_like(gx)), -1).view(-1, 3)
+    grid = base @ (theta.t() / theta.new_tensor([0.5 * W, 0.5 * H]))
+    out = F.grid_sample(img.float().unsqueeze(0), grid.view(1, H, W, 2), mode="nearest",
+                        padding_mode="zeros", align_corners=False)
+    return out[0].to(img.dtype)

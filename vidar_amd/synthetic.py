@@ -54,3 +54,88 @@ def ray_set(seed=0, N=1, T=1, rays_per_frame=30000, grid=(16, 200, 200), pad=0, 
     points = np.ascontiguousarray(points[:, perm]); tindex = np.ascontiguousarray(tindex[:, perm])
     origin = metric_to_voxel(origin_m, Y, X, Z)
     return sigma, origin, points, tindex
+
+
+# --------------------------------------------------------------------------------------------------
+# whole-sample generator for the training step: img_metas with consistent rigid
+# transforms, LiDAR-like GT clouds with the frame index in the last column, FPN feature pyramids.
+# --------------------------------------------------------------------------------------------------
+FPN_SHAPES_NUSC = [(116, 200), (58, 100), (29, 50), (15, 25)]      # 928x1600 input, strides 8..64
+CAM_YAWS_DEG = (0.0, 55.0, -55.0, 110.0, -110.0, 180.0)
+
+
+def _pose(x, y, yaw):
+    c, s = np.cos(yaw), np.sin(yaw)
+    T = np.eye(4)
+    T[:2, :2] = [[c, -s], [s, c]]
+    T[:2, 3] = [x, y]
+    return T
+
+
+def camera_matrices(img_hw=(928, 1600), focal=1266.0, centre=(800.0, 450.0), yaws_deg=CAM_YAWS_DEG):
+    """lidar2img [cams,4,4] of pin-hole cameras looking along the given yaws."""
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = focal
+    K[0, 2], K[1, 2] = centre
+    out = []
+    for d in yaws_deg:
+        a = np.deg2rad(d)
+        R = np.array([[np.sin(a), -np.cos(a), 0.0], [0.0, 0.0, -1.0], [np.cos(a), np.sin(a), 0.0]])
+        C = np.array([0.5 * np.cos(a), 0.5 * np.sin(a), -0.3])
+        E = np.eye(4)
+        E[:3, :3] = R
+        E[:3, 3] = -R @ C
+        out.append(K @ E)
+    return np.stack(out)
+
+
+def make_sample(seed=0, queue_length=4, future_frames=2, rays_per_frame=30000, img_hw=(928, 1600),
+                num_cams=6, first_has_prev=False):
+    """-> (img_metas: list[T] of dict, gt_points [sum P, 5] float32).  T = queue_length + 1 image
+    frames; GT clouds exist for T + future_frames frames (dataset convention
+    datasets/nuscenes_vidar_dataset_v1.py:57-70, :199-200)."""
+    rng = np.random.default_rng(seed)
+    T = queue_length + 1
+    n_all = T + future_frames
+    xs, ys, yaws = [0.0], [0.0], [rng.uniform(-np.pi, np.pi)]
+    for _ in range(1, n_all):
+        xs.append(xs[-1] + rng.normal(0, 2.0)); ys.append(ys[-1] + rng.normal(0, 2.0))
+        yaws.append(yaws[-1] + np.deg2rad(rng.normal(0, 2.0)))
+    poses = [_pose(x, y, a) for x, y, a in zip(xs, ys, yaws)]
+    ref = T - 1
+    inv = np.linalg.inv
+    cur2ref = [(inv(poses[ref]) @ poses[k]).T for k in range(n_all)]     # row-vector convention
+    ref2cur = [(inv(poses[k]) @ poses[ref]).T for k in range(n_all)]
+    lidar2img = camera_matrices(img_hw)[:num_cams]
+    metas = []
+    for k in range(T):
+        can_bus = np.zeros(18)
+        if k > 0:
+            can_bus[:3] = [xs[k] - xs[k - 1], ys[k] - ys[k - 1], 0.0]
+            can_bus[-1] = np.rad2deg(yaws[k] - yaws[k - 1])
+        can_bus[-2] = yaws[k]
+        m = dict(lidar2img=[lidar2img[c] for c in range(num_cams)],
+                 img_shape=[(img_hw[0], img_hw[1], 3)] * num_cams, can_bus=can_bus,
+                 lidar2global_rotation=poses[k][:3, :3].copy(),
+                 prev_bev_exists=bool(k > 0 or first_has_prev),
+                 ref_lidar_to_cur_lidar=ref2cur[k], aug_param=None)
+        metas.append(m)
+    fut = [ref + j for j in range(future_frames + 1)]
+    metas[ref].update(
+        future2ref_lidar_transform=[cur2ref[k] for k in fut],
+        ref2future_lidar_transform=[ref2cur[k] for k in fut],
+        total_cur2ref_lidar_transform=cur2ref, total_ref2cur_lidar_transform=ref2cur,
+        future_can_bus=[np.concatenate([[xs[k] - xs[ref], ys[k] - ys[ref], 0.0], np.zeros(14),
+                                        [np.rad2deg(yaws[k] - yaws[ref])]]) for k in fut])
+    pts = []
+    for k in range(n_all):
+        p = lidar_points(rng, rays_per_frame)
+        pts.append(np.concatenate([p, rng.uniform(0, 1, (rays_per_frame, 1)).astype(np.float32),
+                                   np.full((rays_per_frame, 1), k, np.float32)], 1))
+    return metas, np.concatenate(pts).astype(np.float32)
+
+
+def fpn_features(seed, T, num_cams=6, channels=256, shapes=FPN_SHAPES_NUSC, device="cpu", bs=1):
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return [torch.randn(bs, T, num_cams, channels, h, w, generator=g).to(device) for h, w in shapes]
