@@ -1,0 +1,158 @@
+"""bench.py -- train samples/s of ViDAR's hot path (6-cam FPN features -> BEV encode ->
+latent render -> occupancy head -> ray-march / chamfer losses -> backward -> AdamW) on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU, DDP gradient all-reduce over RCCL.  Prints ONE JSON line on rank 0 with the
+driver contract fields plus `roofline` (dominant HIP kernel, timed live with HIP events on the
+launch stream inside the timed region) and `cpu_baseline` (the CPU oracle port of the same step on a
+bounded sample, rank 0 / N=1 only).  A "sample" = one 5-frame x 6-camera sequence (global batch =
+number of GPUs, the reference asserts 1 sample per GPU: detectors/vidar.py:306)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="vidar_1_8_nusc_1future")
+    ap.add_argument("--rays-per-frame", type=int, default=30000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=2)
+    ap.add_argument("--op-table", action="store_true", help="print the per-op timing table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(config, threads):
+    """The oracle port of the same training step on host cores, bounded sample: BEV 50x50 (1/16 of
+    the 40 000 queries), FPN pyramid of a quarter-resolution input, rays_per_frame/16 GT rays."""
+    from oracle import cpu_ops
+    from vidar_amd import train as T
+    from vidar_amd.configs import get_config
+    from vidar_amd.synthetic import fpn_features, make_sample
+    torch.set_num_threads(threads)
+    cfg = get_config(config, bev_h=50, bev_w=50)
+    torch.manual_seed(0); np.random.seed(0)
+    model = T.build_model(cfg).train()
+    opt = T.build_optimizer(model)
+    metas, gt = make_sample(0, rays_per_frame=30000 // 16, future_frames=cfg["future_frames"],
+                            num_cams=cfg["num_cams"], img_hw=cfg["img_hw"])
+    shapes = [((h + 3) // 4, (w + 3) // 4) for h, w in cfg["fpn_shapes"]]
+    feats = fpn_features(0, 5, num_cams=cfg["num_cams"], shapes=shapes)
+    batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt)], img_feats=feats)
+    with cpu_ops.patched():
+        T.train_step(model, opt, batch)             # warm-up
+        t0 = time.perf_counter()
+        n = 2
+        for _ in range(n):
+            T.train_step(model, opt, batch)
+        dt = (time.perf_counter() - t0) / n
+    scale = 16.0
+    return dict(value=1.0 / (dt * scale), unit="samples/s", cores=threads, kind="port",
+                sample=f"oracle port of the step at BEV 50x50, FPN of a 1/4-res input, 1875 rays/frame: "
+                       f"{dt:.2f} s/step measured, x{scale:.0f} work -> full-size estimate")
+
+
+def main():
+    args = parse()
+    from vidar_amd import train as T
+    from vidar_amd._lib import TIMER
+    from vidar_amd.configs import get_config
+    from vidar_amd.synthetic import fpn_features, make_sample
+
+    rank, local, world = T.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = get_config(args.config)
+    torch.manual_seed(1234)                      # identical initial weights on every rank
+    np.random.seed(1000 + rank)
+    model = T.build_model(cfg).to(dev).train()
+    ddp = T.wrap_ddp(model, local)
+    opt = T.build_optimizer(model)
+    metas, gt = make_sample(seed=100 + rank, queue_length=cfg["queue_length"],
+                            future_frames=cfg["future_frames"], rays_per_frame=args.rays_per_frame,
+                            num_cams=cfg["num_cams"], img_hw=cfg["img_hw"])
+    feats = fpn_features(200 + rank, cfg["queue_length"] + 1, num_cams=cfg["num_cams"],
+                         shapes=cfg["fpn_shapes"], device=dev)
+    batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)], img_feats=feats)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        T.train_step(ddp, opt, batch, cfg["grad_clip"])
+    TIMER.reset()
+    TIMER.enabled = True
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T.train_step(ddp, opt, batch, cfg["grad_clip"])
+    sync()
+    elapsed = time.perf_counter() - t0
+    TIMER.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        ops = TIMER.summary()
+        if args.op_table:
+            for k, v in sorted(ops.items(), key=lambda kv: -kv[1]["total_ms"]):
+                gb = v["bytes_per_call"] / v["avg_ms"] / 1e6 if v["avg_ms"] > 0 else 0
+                print(f"{k:28s} calls/step {v['calls'] / args.steps:6.1f}  avg {v['avg_ms']:8.3f} ms  "
+                      f"total/step {v['total_ms'] / args.steps:8.2f} ms  alg {gb:8.1f} GB/s", file=sys.stderr)
+        dom_name, dom = max(ops.items(), key=lambda kv: kv[1]["total_ms"])
+        achieved = dom["bytes_per_call"] / (dom["avg_ms"] * 1e-3) / 1e9
+        hip_ms = sum(v["total_ms"] for v in ops.values()) / args.steps
+        out = {
+            "metric": "train samples/sec (6-cam->BEV step)", "value": world * args.steps / elapsed,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config} hot path: FPN features [1,5,{cfg['num_cams']},256,"
+                                   f"{cfg['fpn_shapes'][0][0]}x{cfg['fpn_shapes'][0][1]}..] -> 5x BEV encode "
+                                   f"(6 layers TSA+SCA, LatentRendering, bev 200x200) -> head -> ray CE + "
+                                   f"gumbel render + chamfer -> backward -> AdamW; image backbone not included "
+                                   f"(SURVEY §8f row 1)",
+                       "global_batch": world, "rays_per_frame": args.rays_per_frame,
+                       "parallelism": f"dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "avg_ms": dom["avg_ms"], "launches_per_step": dom["calls"] / args.steps,
+                         "hip_ops_ms_per_step": hip_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.config, os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,3 +45,57 @@ def ptr(t):
 def stream_of(t):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# --------------------------------------------------------------------------------------------------
+# optional per-op timing with HIP events on torch's current stream (the stream every op launches on).
+# Disabled by default (zero overhead beyond one attribute test); bench.py switches it on to
+# measure the dominant kernel live inside the timed region.
+# --------------------------------------------------------------------------------------------------
+class OpTimer:
+    def __init__(self):
+        self.enabled = False
+        self.records = {}          # name -> list[(start_event, end_event, algorithmic_bytes)]
+
+    def reset(self):
+        self.records = {}
+
+    class _Span:
+        __slots__ = ("t", "name", "nbytes", "e0")
+
+        def __init__(self, t, name, nbytes):
+            self.t, self.name, self.nbytes = t, name, nbytes
+
+        def __enter__(self):
+            import torch
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+        def __exit__(self, *exc):
+            import torch
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.t.records.setdefault(self.name, []).append((self.e0, e1, self.nbytes))
+
+    class _Null:
+        def __enter__(self): return None
+        def __exit__(self, *exc): return False
+
+    _null = _Null()
+
+    def span(self, name, nbytes=0):
+        return OpTimer._Span(self, name, nbytes) if self.enabled else OpTimer._null
+
+    def summary(self):
+        """name -> dict(calls, total_ms, avg_ms, bytes_per_call) ; synchronises."""
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[name] = dict(calls=len(ms), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                             bytes_per_call=sum(r[2] for r in recs) / len(recs))
+        return out
+
+
+TIMER = OpTimer()

@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ..._lib import lib, check, ptr, stream_of
+from ..._lib import lib, check, ptr, stream_of, TIMER
 
 K_SAMPLES = 512
 
@@ -29,7 +29,8 @@ class _RayCE(Function):
         sigma, origin, gt, tindex = _f(sigma), _f(origin), _f(gt), _f(tindex)
         F_, R, Z, Y, X = _dims(sigma, gt)
         ce = torch.empty(R, device=sigma.device); lse = torch.empty_like(ce); valid = torch.empty_like(ce)
-        check(lib().vidar_ray_ce_fwd_f32(ptr(sigma), ptr(origin), ptr(gt), ptr(tindex), ptr(ce),
+        with TIMER.span("ray_ce_fwd", 4 * (sigma.numel() + R * 7)):
+          check(lib().vidar_ray_ce_fwd_f32(ptr(sigma), ptr(origin), ptr(gt), ptr(tindex), ptr(ce),
                                          ptr(lse), ptr(valid), F_, R, Z, Y, X, K,
                                          ctypes.c_float(step), stream_of(sigma)), "ray_ce_fwd")
         ctx.save_for_backward(sigma, origin, gt, tindex, lse)
@@ -44,7 +45,8 @@ class _RayCE(Function):
         step, K = ctx.cfg
         F_, R, Z, Y, X = _dims(sigma, gt)
         g = torch.empty_like(sigma)
-        check(lib().vidar_ray_ce_bwd_f32(ptr(sigma), ptr(origin), ptr(gt), ptr(tindex), ptr(lse),
+        with TIMER.span("ray_ce_bwd", 4 * (2 * sigma.numel() + R * 6)):
+          check(lib().vidar_ray_ce_bwd_f32(ptr(sigma), ptr(origin), ptr(gt), ptr(tindex), ptr(lse),
                                          ptr(_f(grad_ce)), ptr(g), F_, R, Z, Y, X, K,
                                          ctypes.c_float(step), stream_of(sigma)), "ray_ce_bwd")
         return g, None, None, None, None, None
@@ -58,7 +60,8 @@ class _RayGumbel(Function):
         if noise.shape != (R, K):
             raise RuntimeError(f"noise must be [{R},{K}]")
         dist = torch.empty(R, device=sigma.device); aux = torch.empty((R, 3), device=sigma.device)
-        check(lib().vidar_ray_gumbel_fwd_f32(ptr(sigma), ptr(origin), ptr(pts), ptr(tindex),
+        with TIMER.span("ray_gumbel_fwd", 4 * (sigma.numel() + R * (K + 8))):
+          check(lib().vidar_ray_gumbel_fwd_f32(ptr(sigma), ptr(origin), ptr(pts), ptr(tindex),
                                              ptr(noise), ptr(dist), ptr(aux), F_, R, Z, Y, X, K,
                                              ctypes.c_float(step), stream_of(sigma)), "ray_gumbel_fwd")
         ctx.save_for_backward(sigma, origin, pts, tindex, aux)
@@ -72,7 +75,8 @@ class _RayGumbel(Function):
         step, K = ctx.cfg
         F_, R, Z, Y, X = _dims(sigma, pts)
         g = torch.empty_like(sigma)
-        check(lib().vidar_ray_gumbel_bwd_f32(ptr(sigma), ptr(origin), ptr(pts), ptr(tindex), ptr(aux),
+        with TIMER.span("ray_gumbel_bwd", 4 * (2 * sigma.numel() + R * 8)):
+          check(lib().vidar_ray_gumbel_bwd_f32(ptr(sigma), ptr(origin), ptr(pts), ptr(tindex), ptr(aux),
                                              ptr(_f(grad_dist)), ptr(g), F_, R, Z, Y, X, K,
                                              ctypes.c_float(step), stream_of(sigma)), "ray_gumbel_bwd")
         return g, None, None, None, None, None, None

@@ -7,7 +7,17 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ..._lib import lib, check, ptr, stream_of
+from ..._lib import lib, check, ptr, stream_of, TIMER
+
+
+def msda_fwd_bytes(B, Nv, H, C, Nq, L, P):
+    """ALGORITHMIC bytes: value + (loc, w) + out, each element once."""
+    return 4 * (B * Nv * H * C + B * Nq * H * L * P * 3 + B * Nq * H * C)
+
+
+def msda_bwd_bytes(B, Nv, H, C, Nq, L, P):
+    return msda_fwd_bytes(B, Nv, H, C, Nq, L, P) + 4 * (B * Nq * H * C + B * Nv * H * C
+                                                       + B * Nq * H * L * P * 3)
 
 
 def _msda_forward(value, shapes, lsi, loc, w):
@@ -16,8 +26,9 @@ def _msda_forward(value, shapes, lsi, loc, w):
     if H2 != H or two != 2 or w.shape != (B, Nq, H, L, P):
         raise RuntimeError("inconsistent MSDA operand shapes")
     out = torch.empty((B, Nq, H * C), dtype=torch.float32, device=value.device)
-    check(lib().vidar_msda_fwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w), ptr(out),
-                                   B, Nv, H, C, Nq, L, P, stream_of(value)), "ms_deform_attn_forward")
+    with TIMER.span(f"msda_fwd[L={L},P={P}]", msda_fwd_bytes(B, Nv, H, C, Nq, L, P)):
+        check(lib().vidar_msda_fwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w), ptr(out),
+                                       B, Nv, H, C, Nq, L, P, stream_of(value)), "ms_deform_attn_forward")
     return out
 
 
@@ -27,9 +38,10 @@ def _msda_backward(value, shapes, lsi, loc, w, grad_out):
     gv = torch.empty_like(value)
     gl = torch.empty_like(loc)
     gw = torch.empty_like(w)
-    check(lib().vidar_msda_bwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w), ptr(grad_out),
-                                   ptr(gv), ptr(gl), ptr(gw), B, Nv, H, C, Nq, L, P,
-                                   stream_of(value)), "ms_deform_attn_backward")
+    with TIMER.span(f"msda_bwd[L={L},P={P}]", msda_bwd_bytes(B, Nv, H, C, Nq, L, P)):
+        check(lib().vidar_msda_bwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w),
+                                       ptr(grad_out), ptr(gv), ptr(gl), ptr(gw), B, Nv, H, C, Nq, L, P,
+                                       stream_of(value)), "ms_deform_attn_backward")
     return gv, gl, gw
 
 

@@ -14,7 +14,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from ...registry import ATTENTION
-from ...._lib import lib, check, ptr, stream_of
+from ...._lib import lib, check, ptr, stream_of, TIMER
 
 _ACT = {"sigmoid": 0, "exp": 1}
 
@@ -31,7 +31,8 @@ class _PathProb(Function):
         occ = occ.float().contiguous()
         prob = torch.empty_like(occ)
         step = _step(grid_step, H, W)
-        check(lib().vidar_latent_render_prob_fwd_f32(ptr(occ), ptr(prob), bs, H, W, Z, grid_num,
+        with TIMER.span("lr_prob_fwd", 4 * occ.numel() * 2):
+          check(lib().vidar_latent_render_prob_fwd_f32(ptr(occ), ptr(prob), bs, H, W, Z, grid_num,
                                                      ctypes.c_float(step), act, stream_of(occ)),
               "latent_render_prob_fwd")
         ctx.save_for_backward(occ)
@@ -45,7 +46,8 @@ class _PathProb(Function):
         grid_num, step, act = ctx.cfg
         bs, H, W, Z = occ.shape
         g = torch.empty_like(occ)
-        check(lib().vidar_latent_render_prob_bwd_f32(ptr(occ), ptr(grad_prob.float().contiguous()),
+        with TIMER.span("lr_prob_bwd", 4 * occ.numel() * 3):
+          check(lib().vidar_latent_render_prob_bwd_f32(ptr(occ), ptr(grad_prob.float().contiguous()),
                                                      ptr(g), bs, H, W, Z, grid_num,
                                                      ctypes.c_float(step), act, stream_of(occ)),
               "latent_render_prob_bwd")
@@ -59,7 +61,8 @@ class _RayGather(Function):
         prob = prob.float().contiguous(); a = a.float().contiguous()
         feat = torch.empty_like(prob); msum = torch.empty_like(prob)
         step = _step(grid_step, H, W)
-        check(lib().vidar_latent_render_gather_fwd_f32(ptr(prob), ptr(a), ptr(feat), ptr(msum), bs, H,
+        with TIMER.span("lr_gather_fwd", 4 * prob.numel() * 4):
+          check(lib().vidar_latent_render_gather_fwd_f32(ptr(prob), ptr(a), ptr(feat), ptr(msum), bs, H,
                                                        W, Z, grid_num, ctypes.c_float(step),
                                                        ctypes.c_float(eps), stream_of(prob)),
               "latent_render_gather_fwd")
@@ -74,7 +77,8 @@ class _RayGather(Function):
         grid_num, step, eps = ctx.cfg
         bs, H, W, Z = prob.shape
         gp = torch.empty_like(prob); ga = torch.empty_like(a)
-        check(lib().vidar_latent_render_gather_bwd_f32(ptr(prob), ptr(a), ptr(feat), ptr(msum),
+        with TIMER.span("lr_gather_bwd", 4 * prob.numel() * 7):
+          check(lib().vidar_latent_render_gather_bwd_f32(ptr(prob), ptr(a), ptr(feat), ptr(msum),
                                                        ptr(grad_feat.float().contiguous()), ptr(gp),
                                                        ptr(ga), bs, H, W, Z, grid_num,
                                                        ctypes.c_float(step), ctypes.c_float(eps),

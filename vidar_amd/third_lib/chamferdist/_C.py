@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import torch
 
-from ..._lib import lib, check, ptr, stream_of
+from ..._lib import lib, check, ptr, stream_of, TIMER
 
 
 def knn_check_version(version: int, D: int, K: int) -> bool:
@@ -37,7 +37,8 @@ def knn_points_idx(p1, p2, lengths1, lengths2, K: int = 1, version: int = -1):
     idx = torch.empty((N, P1, 1), dtype=torch.int64, device=p1.device)
     dist = torch.empty((N, P1, 1), dtype=torch.float32, device=p1.device)
     ws = torch.empty((max(N * P1, 1),), dtype=torch.int64, device=p1.device)
-    check(lib().vidar_knn1_d3_fwd(ptr(p1), ptr(p2), ptr(l1), ptr(l2), ptr(idx), ptr(dist), ptr(ws),
+    with TIMER.span("knn1_d3_fwd", 12 * (N * P1 + N * P2) + 12 * N * P1):
+      check(lib().vidar_knn1_d3_fwd(ptr(p1), ptr(p2), ptr(l1), ptr(l2), ptr(idx), ptr(dist), ptr(ws),
                                   N, P1, P2, stream_of(p1)), "knn_points_idx")
     return idx, dist
 

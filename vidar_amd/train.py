@@ -15,7 +15,10 @@ from .plugin.config import Config
 
 
 def build_model(cfg, bev_hw=None):
-    model_cfg = dict(cfg.model) if isinstance(cfg, Config) else dict(cfg)
+    if isinstance(cfg, Config):
+        model_cfg = dict(cfg.model)
+    else:
+        model_cfg = dict(cfg["model"]) if "model" in cfg and "type" not in cfg else dict(cfg)
     if bev_hw is not None:
         model_cfg = _resize_bev(model_cfg, *bev_hw)
     model = plugin.build_detector(model_cfg)
