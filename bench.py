@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--config", default="vidar_1_8_nusc_1future")
     ap.add_argument("--rays-per-frame", type=int, default=30000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=2)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 16))
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=240)
     ap.add_argument("--op-table", action="store_true", help="print the per-op timing table to stderr")
     return ap.parse_args()
 
@@ -63,7 +65,7 @@ def cpu_baseline(config, threads):
     with cpu_ops.patched():
         T.train_step(model, opt, batch)             # warm-up
         t0 = time.perf_counter()
-        n = 2
+        n = 1
         for _ in range(n):
             T.train_step(model, opt, batch)
         dt = (time.perf_counter() - t0) / n
@@ -73,8 +75,28 @@ def cpu_baseline(config, threads):
                        f"{dt:.2f} s/step measured, x{scale:.0f} work -> full-size estimate")
 
 
+def cpu_baseline_subprocess(args):
+    """Run the CPU leg in a child with a hard wall-clock limit so it can never stall the bench."""
+    import subprocess
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--config", args.config,
+           "--cpu-threads", str(args.cpu_threads)]
+    env = dict(os.environ, OMP_NUM_THREADS=str(args.cpu_threads), MKL_NUM_THREADS=str(args.cpu_threads))
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout, env=env)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        note = "cpu leg produced no result: " + r.stderr.strip()[-200:]
+    except subprocess.TimeoutExpired:
+        note = f"cpu leg exceeded {args.cpu_baseline_timeout} s and was stopped"
+    return dict(value=None, unit="samples/s", cores=args.cpu_threads, kind="port", sample=note)
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.config, args.cpu_threads)), flush=True)
+        return
     from vidar_amd import train as T
     from vidar_amd._lib import TIMER
     from vidar_amd.configs import get_config
@@ -147,7 +169,8 @@ def main():
                          "hip_ops_ms_per_step": hip_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline_subprocess(args)
+            out["cpu_baseline"]["host_cores"] = os.cpu_count()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -140,6 +140,26 @@ __device__ __forceinline__ float4 ksum(float4 v) {
   return v;
 }
 
+
+// ---- backward mapping: lane = (waypoint k mod 4, height bin z): one atomic instruction covers the
+// ---- 64 contiguous bytes of a tap corner (atomics cost per instruction x line, see msda.hip) ------
+__device__ __forceinline__ float tap_load1(const float* __restrict__ map, const Tap& t, int z) {
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (t.o[c] >= 0) acc += t.w[c] * map[(size_t)t.o[c] * kZ + z];
+  return acc;
+}
+__device__ __forceinline__ void tap_scatter1(float* __restrict__ map, const Tap& t, int z, float g) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (t.o[c] >= 0) unsafeAtomicAdd(map + (size_t)t.o[c] * kZ + z, t.w[c] * g);
+}
+__device__ __forceinline__ float kprod1(float v) {
+  v *= __shfl_xor(v, 16, 64); v *= __shfl_xor(v, 32, 64);
+  return v;
+}
+
 __device__ __forceinline__ void waypoint(const Cell& c, const Geo& g, int k, float& nx, float& ny,
                                          float& len) {
   const float s = (k + 0.5f) * g.step;
@@ -185,51 +205,36 @@ __global__ __launch_bounds__(kThreads) void lr_prob_bwd_kernel(const float* __re
   const int b = blockIdx.y;
   const int q = blockIdx.x * kCellsPerBlock + threadIdx.x / 64;
   if (q >= Q) return;
-  const int lane = threadIdx.x & 63, zq = lane & 3, ks = lane >> 2;
+  const int lane = threadIdx.x & 63, z = lane & 15, ks = lane >> 4;
   const float* map = occ + (size_t)b * Q * kZ;
   float* gmap = grad_occ + (size_t)b * Q * kZ;
   const Cell c = make_cell(q, g);
   // pass 1: the transmittance product
-  float4 pr = make_float4(1.f, 1.f, 1.f, 1.f);
-  for (int k = ks; k < g.G; k += 16) {
+  float pr = 1.f;
+  for (int k = ks; k < g.G; k += 4) {
     float nx, ny, len;
     waypoint(c, g, k, nx, ny, len);
-    if (len < c.len_c) {
-      const float4 p = act4(tap_load(map, make_tap(nx, ny, g), zq), g.act);
-      pr.x *= 1.f - p.x; pr.y *= 1.f - p.y; pr.z *= 1.f - p.z; pr.w *= 1.f - p.w;
-    }
+    if (len < c.len_c) pr *= 1.f - act_f(tap_load1(map, make_tap(nx, ny, g), z), g.act);
   }
-  pr = kprod(pr);
+  pr = kprod1(pr);
   const Tap tc = make_tap(c.ncx, c.ncy, g);
-  const float4 xc = tap_load(map, tc, zq);
-  const float4 pc = act4(xc, g.act);
-  const float4 go = *reinterpret_cast<const float4*>(grad_prob + ((size_t)b * Q + q) * kZ + zq * 4);
+  const float xc = tap_load1(map, tc, z);
+  const float pc = act_f(xc, g.act);
+  const float go = grad_prob[((size_t)b * Q + q) * kZ + z];
   // d/d(1-p_k) of prod * pc  = prod/(1-p_k) * pc ; guarded against (1-p_k) == 0
-  const float4 gp = make_float4(go.x * pr.x * pc.x, go.y * pr.y * pc.y, go.z * pr.z * pc.z,
-                                go.w * pr.w * pc.w);
-  for (int k = ks; k < g.G; k += 16) {
+  const float gp = go * pr * pc;
+  for (int k = ks; k < g.G; k += 4) {
     float nx, ny, len;
     waypoint(c, g, k, nx, ny, len);
     if (len < c.len_c) {
       const Tap t = make_tap(nx, ny, g);
-      const float4 x = tap_load(map, t, zq);
-      const float4 p = act4(x, g.act);
-      float4 gs;
-      gs.x = (1.f - p.x) > 0.f ? -gp.x / (1.f - p.x) * act_d(x.x, p.x, g.act) : 0.f;
-      gs.y = (1.f - p.y) > 0.f ? -gp.y / (1.f - p.y) * act_d(x.y, p.y, g.act) : 0.f;
-      gs.z = (1.f - p.z) > 0.f ? -gp.z / (1.f - p.z) * act_d(x.z, p.z, g.act) : 0.f;
-      gs.w = (1.f - p.w) > 0.f ? -gp.w / (1.f - p.w) * act_d(x.w, p.w, g.act) : 0.f;
-      tap_scatter(gmap, t, zq, gs);
+      const float x = tap_load1(map, t, z);
+      const float p = act_f(x, g.act);
+      const float gs = (1.f - p) > 0.f ? -gp / (1.f - p) * act_d(x, p, g.act) : 0.f;
+      tap_scatter1(gmap, t, z, gs);
     }
   }
-  if (ks == 0) {
-    float4 gs;
-    gs.x = go.x * pr.x * act_d(xc.x, pc.x, g.act);
-    gs.y = go.y * pr.y * act_d(xc.y, pc.y, g.act);
-    gs.z = go.z * pr.z * act_d(xc.z, pc.z, g.act);
-    gs.w = go.w * pr.w * act_d(xc.w, pc.w, g.act);
-    tap_scatter(gmap, tc, zq, gs);
-  }
+  if (ks == 0) tap_scatter1(gmap, tc, z, go * pr * act_d(xc, pc, g.act));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,29 +281,24 @@ __global__ __launch_bounds__(kThreads) void lr_gather_bwd_kernel(
   const int b = blockIdx.y;
   const int q = blockIdx.x * kCellsPerBlock + threadIdx.x / 64;
   if (q >= Q) return;
-  const int lane = threadIdx.x & 63, zq = lane & 3, ks = lane >> 2;
+  const int lane = threadIdx.x & 63, z = lane & 15, ks = lane >> 4;
   const float* pm = prob + (size_t)b * Q * kZ;
   const float* am = a + (size_t)b * Q * kZ;
   float* gpm = grad_prob + (size_t)b * Q * kZ;
   float* gam = grad_a + (size_t)b * Q * kZ;
   const Cell c = make_cell(q, g);
-  const size_t o = ((size_t)b * Q + q) * kZ + zq * 4;
-  const float4 f = *reinterpret_cast<const float4*>(feat + o);
-  const float4 M = *reinterpret_cast<const float4*>(msum + o);
-  const float4 go = *reinterpret_cast<const float4*>(grad_feat + o);
-  // s = grad / (M + eps)
-  const float4 s = make_float4(go.x / (M.x + g.eps), go.y / (M.y + g.eps), go.z / (M.z + g.eps),
-                               go.w / (M.w + g.eps));
-  for (int k = ks; k < g.G; k += 16) {
+  const size_t o = ((size_t)b * Q + q) * kZ + z;
+  const float f = feat[o];
+  const float s = grad_feat[o] / (msum[o] + g.eps);
+  for (int k = ks; k < g.G; k += 4) {
     float nx, ny, len;
     waypoint(c, g, k, nx, ny, len);
     if (len < c.bound) {
       const Tap t = make_tap(nx, ny, g);
-      const float4 m = tap_load(pm, t, zq);
-      const float4 av = tap_load(am, t, zq);
-      tap_scatter(gam, t, zq, make_float4(s.x * m.x, s.y * m.y, s.z * m.z, s.w * m.w));
-      tap_scatter(gpm, t, zq, make_float4(s.x * (av.x - f.x), s.y * (av.y - f.y),
-                                          s.z * (av.z - f.z), s.w * (av.w - f.w)));
+      const float m = tap_load1(pm, t, z);
+      const float av = tap_load1(am, t, z);
+      tap_scatter1(gam, t, z, s * m);
+      tap_scatter1(gpm, t, z, s * (av - f));
     }
   }
 }

@@ -18,8 +18,7 @@
 // (they are contiguous in HBM) and re-read as broadcasts.  Workgroups are remapped so that each
 // XCD walks a contiguous band of queries: neighbouring BEV queries sample neighbouring pixels, so
 // a band keeps its slice of `value` resident in that XCD's private 4 MiB L2.
-// Backward: grad_value by fp32 hardware atomics; grad_loc / grad_w reduce over the 32 channels
-// with three xor-shuffles inside the 8-lane group and leave through LDS as coalesced stores.
+// Backward: see the comment above msda_bwd_kernel (one atomic instruction per 128-byte corner line).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -115,22 +114,23 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
   *reinterpret_cast<float4*>(out + item * kCh + sub * 4) = acc;
 }
 
-__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
-  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-}
-__device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
+// ---------------------------------------------------------------------------------------------
+// backward.  Measured on MI355X (tools/micro/atomic_bench.hip): fp32 global atomics retire at
+// ~10 G (instruction x 128-byte line) requests per second no matter how many dwords of the line an
+// instruction touches.  So the scatter uses ONE instruction per corner line: 32 adjacent lanes own
+// the 32 channels of a head (two items per wave).  grad_loc / grad_w reduce over those 32 lanes
+// with xor shuffles and leave through LDS as coalesced stores.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBLanes = 32;
+constexpr int kBItems = kThreads / kBLanes;   // 8 items per workgroup
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < kBLanes; m <<= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
-__device__ __forceinline__ void atomic_add4(float* __restrict__ p, int64_t o, float s,
-                                            const float4& g) {
-  if (o < 0) return;
-  unsafeAtomicAdd(p + o + 0, s * g.x);
-  unsafeAtomicAdd(p + o + 1, s * g.y);
-  unsafeAtomicAdd(p + o + 2, s * g.z);
-  unsafeAtomicAdd(p + o + 3, s * g.w);
+__device__ __forceinline__ float ld1(const float* __restrict__ p, int64_t o) {
+  return o >= 0 ? p[o] : 0.f;
 }
 
 __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
@@ -141,26 +141,26 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
     int64_t n_items, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
-  float* s_loc = smem;                        // [kItems][LP*2]  in: loc, out: grad_loc
-  float* s_w = smem + kItems * LP * 2;        // [kItems][LP]    in: w,   out: grad_w
+  float* s_loc = smem;                         // [kBItems][LP*2]  in: loc, out: grad_loc
+  float* s_w = smem + kBItems * LP * 2;        // [kBItems][LP]    in: w,   out: grad_w
   const int blk = xcd_remap(blockIdx.x, nblocks);
   if (blk >= nblocks) return;
-  const int64_t item0 = (int64_t)blk * kItems;
-  const int nvalid = (int)min((int64_t)kItems, n_items - item0);
+  const int64_t item0 = (int64_t)blk * kBItems;
+  const int nvalid = (int)min((int64_t)kBItems, n_items - item0);
   for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) s_loc[i] = loc[item0 * LP * 2 + i];
   for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) s_w[i] = attw[item0 * LP + i];
   __syncthreads();
-  const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
+  const int it = threadIdx.x / kBLanes, ch = threadIdx.x % kBLanes;
   if (it < nvalid) {
     const int64_t item = item0 + it;
     const int h = (int)(item % H);
     const int64_t bq = item / H;
     const int b = (int)(bq / Nq);
     const int row_stride = H * kCh;
-    const int64_t voff = (int64_t)b * Nv * row_stride + h * kCh + sub * 4;
+    const int64_t voff = (int64_t)b * Nv * row_stride + h * kCh + ch;
     const float* vb = value + voff;
     float* gvb = grad_value + voff;
-    const float4 go = *reinterpret_cast<const float4*>(grad_out + item * kCh + sub * 4);
+    const float go = grad_out[item * kCh + ch];
     float* ml = s_loc + it * LP * 2;
     float* mw = s_w + it * LP;
     for (int l = 0; l < L; ++l) {
@@ -171,25 +171,23 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
         const float y = ml[(l * P + p) * 2 + 1] * Hl - 0.5f;
         const float w = mw[l * P + p];
         float gx = 0.f, gy = 0.f, gw = 0.f;
-        if (y > -1.f && x > -1.f && y < Hl && x < Wl) {
+        if (y > -1.f && x > -1.f && y < Hl && x < Wl) {     // uniform over the item's 32 lanes
           const Corner c = corners(x, y, Hl, Wl, base, row_stride);
-          const float4 v00 = ld4(vb, c.o00), v01 = ld4(vb, c.o01), v10 = ld4(vb, c.o10),
-                       v11 = ld4(vb, c.o11);
-          const float d00 = dot4(v00, go), d01 = dot4(v01, go), d10 = dot4(v10, go),
-                      d11 = dot4(v11, go);
+          const float d00 = ld1(vb, c.o00) * go, d01 = ld1(vb, c.o01) * go,
+                      d10 = ld1(vb, c.o10) * go, d11 = ld1(vb, c.o11) * go;
           const float hh = 1.f - c.lh, hw = 1.f - c.lw;
           gw = c.w00 * d00 + c.w01 * d01 + c.w10 * d10 + c.w11 * d11;
           gx = w * Wl * (-hh * d00 + hh * d01 - c.lh * d10 + c.lh * d11);
           gy = w * Hl * (-hw * d00 - c.lw * d01 + hw * d10 + c.lw * d11);
-          atomic_add4(gvb, c.o00, w * c.w00, go);
-          atomic_add4(gvb, c.o01, w * c.w01, go);
-          atomic_add4(gvb, c.o10, w * c.w10, go);
-          atomic_add4(gvb, c.o11, w * c.w11, go);
+          const float wg = w * go;
+          if (c.o00 >= 0) unsafeAtomicAdd(gvb + c.o00, c.w00 * wg);
+          if (c.o01 >= 0) unsafeAtomicAdd(gvb + c.o01, c.w01 * wg);
+          if (c.o10 >= 0) unsafeAtomicAdd(gvb + c.o10, c.w10 * wg);
+          if (c.o11 >= 0) unsafeAtomicAdd(gvb + c.o11, c.w11 * wg);
         }
-        gx = group_sum(gx); gy = group_sum(gy); gw = group_sum(gw);
-        // every lane of the group has consumed (x, y, w) of this point before the shuffles
-        // completed, so lane 0 may overwrite the staged inputs with the gradients
-        if (sub == 0) {
+        gx = half_wave_sum(gx); gy = half_wave_sum(gy); gw = half_wave_sum(gw);
+        // all 32 lanes consumed (x, y, w) of this point before the shuffles finished
+        if (ch == 0) {
           ml[(l * P + p) * 2] = gx;
           ml[(l * P + p) * 2 + 1] = gy;
           mw[l * P + p] = gw;
@@ -242,9 +240,9 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
   }
   const int64_t n_items = (int64_t)B * Nq * H;
   if (n_items == 0) return 0;
-  const int nblocks = (int)((n_items + kItems - 1) / kItems);
+  const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
   const int grid = ((nblocks + 7) / 8) * 8;
-  const size_t lds = sizeof(float) * kItems * L * P * 3;
+  const size_t lds = sizeof(float) * kBItems * L * P * 3;
   hipLaunchKernelGGL(msda_bwd_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                      level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
                      grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks);
