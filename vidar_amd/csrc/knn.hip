@@ -99,11 +99,13 @@ __global__ __launch_bounds__(256) void knn1_d3_bwd_kernel(
   if (i < len1[n] && len2[n] > 0) {
     const int64_t j = idx[(size_t)n * P1 + i];
     const float g2 = 2.0f * grad_dist[(size_t)n * P1 + i];
-    const float* a = p1 + ((size_t)n * P1 + i) * 3;
-    const float* b = p2 + ((size_t)n * P2 + j) * 3;
-    gx = g2 * (a[0] - b[0]); gy = g2 * (a[1] - b[1]); gz = g2 * (a[2] - b[2]);
-    float* o = grad_p2 + ((size_t)n * P2 + j) * 3;
-    unsafeAtomicAdd(o + 0, -gx); unsafeAtomicAdd(o + 1, -gy); unsafeAtomicAdd(o + 2, -gz);
+    if (g2 != 0.f) {     // adding +-0 is the identity; skipping it avoids same-address atomic storms
+      const float* a = p1 + ((size_t)n * P1 + i) * 3;
+      const float* b = p2 + ((size_t)n * P2 + j) * 3;
+      gx = g2 * (a[0] - b[0]); gy = g2 * (a[1] - b[1]); gz = g2 * (a[2] - b[2]);
+      float* o = grad_p2 + ((size_t)n * P2 + j) * 3;
+      unsafeAtomicAdd(o + 0, -gx); unsafeAtomicAdd(o + 1, -gy); unsafeAtomicAdd(o + 2, -gz);
+    }
   }
   float* o1 = grad_p1 + ((size_t)n * P1 + i) * 3;
   o1[0] = gx; o1[1] = gy; o1[2] = gz;

@@ -69,7 +69,7 @@ class ViDARHeadV1(ViDARHeadBase):
             slot = slot_of[frame]                                      # [-1 index hits the -1 tail]
             m = src_to_tgt[b][slot.clamp(min=0).long()]               # [P, 4, 4]
             hom = torch.cat([p[:, :3], p.new_ones(p.shape[0], 1)], 1)
-            moved = torch.einsum("pi,pij->pj", hom, m)
+            moved = (hom.unsqueeze(-1) * m).sum(1)          # row-vector x per-point 4x4, elementwise
             out.append(torch.cat([moved[:, :3], slot[:, None]], 1))
         return out, origin
 

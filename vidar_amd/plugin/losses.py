@@ -18,14 +18,21 @@ def chamfer_distance(src, dst, src_weight=1.0, dst_weight=1.0, criterion_mode="l
 
     Extension (not in mmdet3d): `dst_valid` [B,M] bool keeps the tensor shapes static -- invalid
     target points are ignored exactly as if they had been removed before the call (no host sync):
-    they can never be a nearest neighbour and 'mean' divides by the number of valid points."""
+    they can never be a nearest neighbour and 'mean' divides by the number of valid points.
+    With `dst_valid` the returned indices refer to the valid-first permutation of `dst`."""
     if criterion_mode != "l2":
         raise NotImplementedError("only criterion_mode='l2' is on ViDAR's path")
+    lengths = None
     if dst_valid is not None:
-        keep = dst_valid.unsqueeze(-1)
-        dst = torch.where(keep, torch.nan_to_num(dst), dst.new_full((), FAR))
-    fwd = knn_points(src, dst)
-    bwd = knn_points(dst, src)
+        # stable partition: valid points first, their count stays on the device as `lengths`
+        # (the KNN kernels read lengths on device and skip everything beyond them)
+        order = torch.argsort((~dst_valid).to(torch.int8), dim=1, stable=True)
+        dst = torch.gather(torch.nan_to_num(dst), 1, order.unsqueeze(-1).expand(-1, -1, dst.shape[-1]))
+        dst_valid = torch.gather(dst_valid, 1, order)
+        lengths = dst_valid.sum(1).to(torch.int64)
+        dst = torch.where(dst_valid.unsqueeze(-1), dst, dst.new_full((), FAR))
+    fwd = knn_points(src, dst, lengths2=lengths)
+    bwd = knn_points(dst, src, lengths1=lengths)
     loss_src = fwd.dists[..., 0] * src_weight
     loss_dst = bwd.dists[..., 0] * dst_weight
     if dst_valid is not None:
