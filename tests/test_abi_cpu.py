@@ -1,0 +1,51 @@
+"""CPU: libvidar_hip.so builds for gfx950, loads, and exports every symbol include/vidar_hip.h
+declares (no compute calls without a GPU); the product fails loudly without its library/GPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "vidar_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vidar_\w+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from vidar_amd import build
+    lib_path = build.build(verbose=False)
+    lib = ctypes.CDLL(str(lib_path))
+    names = declared_symbols()
+    assert len(names) >= 24
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in vidar_hip.h but not exported: {missing}"
+    assert lib.vidar_abi_version() >= 1
+    assert lib.vidar_dvr_max_d() == 1446 and lib.vidar_dvxlr_max_d() == 1026
+
+
+def test_no_cpu_fallback():
+    """CPU tensors are rejected (CHECK_CUDA semantics), nothing silently runs on the host."""
+    from vidar_amd.third_lib import dvxlr
+    from vidar_amd.third_lib.chamferdist import knn_points
+    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import multi_scale_deformable_attn
+    with pytest.raises(RuntimeError):
+        dvxlr.render(torch.zeros(1, 1, 2, 2, 2), torch.zeros(1, 1, 3), torch.zeros(1, 4, 3), torch.zeros(1, 4))
+    with pytest.raises(RuntimeError):
+        knn_points(torch.zeros(1, 4, 3), torch.zeros(1, 5, 3))
+    with pytest.raises(RuntimeError):
+        multi_scale_deformable_attn(torch.zeros(1, 4, 8, 32), torch.tensor([[2, 2]]), torch.tensor([0]),
+                                    torch.zeros(1, 3, 8, 1, 4, 2), torch.zeros(1, 3, 8, 1, 4))
+
+
+def test_product_never_imports_oracle():
+    for f in (ROOT / "vidar_amd").rglob("*.py"):
+        src = f.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, f
+    for f in (ROOT / "vidar_amd" / "csrc").glob("*"):
+        if f.is_file() and f.suffix in (".hip", ".h"):
+            assert "oracle" not in f.read_text().lower(), f
