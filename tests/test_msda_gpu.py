@@ -14,6 +14,9 @@ CASES = [
     ("pred_small", 1, [(16, 12)], 192, 4),
     ("one", 1, [(1, 1)], 1, 1),
     ("ragged_items", 1, [(9, 7)], 5, 4),          # 40 items: last workgroup partially filled
+    ("bev_self_attn_tiled", 2, [(24, 24)], 576, 4),   # Nv == Nq square grid -> 8x8 tiled write-combining path
+    ("bev_ragged_tiles", 1, [(20, 20)], 400, 4),      # grid not a multiple of the 8x8 tile
+    ("sca_wc", 2, [(30, 50), (15, 25), (8, 13), (4, 7)], 1000, 8),  # multi-level write-combining path
 ]
 
 
