@@ -131,16 +131,6 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
                        int Nq, int L, int P, void* stream);
 
-/* Same as vidar_msda_bwd_f32 plus a locality hint: query_grid_w > 0 states that the L == 1 value map
- * IS the query grid (Nv == Nq, row-major, query_grid_w cells per row: temporal / prediction
- * self-attention over BEV), which lets the kernel tile queries 8x8 for its LDS write-combining
- * table.  0 = no hint.  Results do not depend on the hint. */
-int vidar_msda_bwd_hint_f32(const float* value, const int64_t* spatial_shapes,
-                            const int64_t* level_start_index, const float* sampling_loc,
-                            const float* attn_weight, const float* grad_out, float* grad_value,
-                            float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H,
-                            int C, int Nq, int L, int P, int query_grid_w, void* stream);
-
 /* ---------------------------------------------------------------------------
  * LatentRendering ray-march (fused).  Replaces the torch op chain of
  * projects/mmdet3d_plugin/bevformer/modules/ray_operations/latent_rendering.py:96-150.

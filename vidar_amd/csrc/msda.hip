@@ -200,149 +200,6 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
   for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) grad_w[item0 * LP + i] = s_w[i];
 }
 
-// ---------------------------------------------------------------------------------------------
-// backward, write-combining variant.  A workgroup owns 64 queries x kHB heads and keeps an LDS
-// accumulation table of kSlots (pixel, head) lines (128 B each): corner contributions first meet in
-// LDS (ds_add_f32, conflict-free: 32 lanes = 32 consecutive banks) and every touched line leaves
-// with ONE global atomic request at the end.  Lines that do not find a slot within kProbes probes go
-// straight to global atomics, so the table is an optimisation, never a correctness dependency.
-// Queries are taken as an 8x8 BEV tile when the value map is the query grid itself (temporal /
-// prediction self-attention), otherwise as 64 consecutive queries (camera-compacted SCA queries);
-// for multi-level maps only levels >= 1 use the table (level-0 footprints barely overlap).
-// ---------------------------------------------------------------------------------------------
-constexpr int kHB = 2;              // heads per workgroup
-constexpr int kQB = 64;             // queries per workgroup
-constexpr int kSlots = 512;         // 512 x 128 B = 64 KiB  -> two workgroups per CU
-constexpr int kProbes = 4;
-constexpr int kGroups = kThreads / kBLanes;   // 8 items in flight
-
-__device__ __forceinline__ void wc_add(int* __restrict__ tags, float* __restrict__ acc,
-                                       float* __restrict__ gv_line0, int key, int ch, float val,
-                                       int leader) {
-  unsigned slot = ((unsigned)key * 2654435761u) >> (32 - 9);
-#pragma unroll
-  for (int pr = 0; pr < kProbes; ++pr) {
-    int t = 0;
-    if (ch == 0) t = atomicCAS(&tags[slot], -1, key);
-    t = __shfl(t, leader, 64);
-    if (t == -1 || t == key) {
-      atomicAdd(&acc[slot * kCh + ch], val);
-      return;
-    }
-    slot = (slot + 1) & (kSlots - 1);
-  }
-  unsafeAtomicAdd(gv_line0 + (int64_t)key * kCh + ch, val);
-}
-
-__global__ __launch_bounds__(kThreads) void msda_bwd_wc_kernel(
-    const float* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
-    const float* __restrict__ grad_out, float* __restrict__ grad_value,
-    float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv, int H, int Nq, int L, int P,
-    int tile_w /* >0: queries form a [Nq/tile_w, tile_w] grid and are tiled 8x8 */, int first_tbl_level,
-    int qblocks_per_batch) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LP = L * P;
-  float* acc = smem;                                     // [kSlots][32]
-  int* tags = reinterpret_cast<int*>(smem + kSlots * kCh);       // [kSlots]
-  float* stage = smem + kSlots * kCh + kSlots;           // [kGroups][LP*3]
-  for (int i = threadIdx.x; i < kSlots * kCh; i += kThreads) acc[i] = 0.f;
-  for (int i = threadIdx.x; i < kSlots; i += kThreads) tags[i] = -1;
-  __syncthreads();
-
-  const int hgroups = H / kHB;
-  int bid = blockIdx.x;
-  const int hg = bid % hgroups; bid /= hgroups;
-  const int qb = bid % qblocks_per_batch;
-  const int b = bid / qblocks_per_batch;
-  const int grp = threadIdx.x / kBLanes, ch = threadIdx.x % kBLanes;
-  const int leader = (threadIdx.x & 63) & ~(kBLanes - 1);
-  const int row_stride = H * kCh;
-  float* st_loc = stage + grp * LP * 3;
-  float* st_w = st_loc + LP * 2;
-
-  for (int it = grp; it < kQB * kHB; it += kGroups) {
-    const int qi = it / kHB, h = hg * kHB + it % kHB;
-    int q;
-    if (tile_w > 0) {
-      const int tiles_x = (tile_w + 7) >> 3;
-      const int ty = qb / tiles_x, tx = qb % tiles_x;
-      const int y = ty * 8 + (qi >> 3), x = tx * 8 + (qi & 7);
-      q = (x < tile_w && y * tile_w + x < Nq) ? y * tile_w + x : -1;
-    } else {
-      q = qb * kQB + qi;
-      if (q >= Nq) q = -1;
-    }
-    if (q < 0) continue;                                  // uniform over the 32 lanes of the group
-    const int64_t item = ((int64_t)b * Nq + q) * H + h;
-    // stage this item's sampling locations / weights (wave-synchronous within the group)
-    for (int i = ch; i < LP * 2; i += kBLanes) st_loc[i] = loc[item * LP * 2 + i];
-    for (int i = ch; i < LP; i += kBLanes) st_w[i] = attw[item * LP + i];
-    __builtin_amdgcn_wave_barrier();
-    const float* vb = value + (int64_t)b * Nv * row_stride + h * kCh + ch;
-    const int64_t key_b = (int64_t)b * Nv * H + h;        // line key = (b*Nv + pixel)*H + h
-    const float go = grad_out[item * kCh + ch];
-    for (int l = 0; l < L; ++l) {
-      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-      const int start = (int)lsi[l];
-      const bool tbl = l >= first_tbl_level;
-      for (int p = 0; p < P; ++p) {
-        const float x = st_loc[(l * P + p) * 2] * Wl - 0.5f;
-        const float y = st_loc[(l * P + p) * 2 + 1] * Hl - 0.5f;
-        const float w = st_w[l * P + p];
-        float gx = 0.f, gy = 0.f, gw = 0.f;
-        if (y > -1.f && x > -1.f && y < Hl && x < Wl) {
-          const int h0 = (int)floorf(y), w0 = (int)floorf(x), h1 = h0 + 1, w1 = w0 + 1;
-          const float lh = y - h0, lw = x - w0, hh = 1.f - lh, hw = 1.f - lw;
-          const bool t_ = h0 >= 0, b_ = h1 <= Hl - 1, l_ = w0 >= 0, r_ = w1 <= Wl - 1;
-          const int p00 = (t_ && l_) ? start + h0 * Wl + w0 : -1;
-          const int p01 = (t_ && r_) ? start + h0 * Wl + w1 : -1;
-          const int p10 = (b_ && l_) ? start + h1 * Wl + w0 : -1;
-          const int p11 = (b_ && r_) ? start + h1 * Wl + w1 : -1;
-          const float v00 = p00 >= 0 ? vb[(int64_t)p00 * row_stride] : 0.f;
-          const float v01 = p01 >= 0 ? vb[(int64_t)p01 * row_stride] : 0.f;
-          const float v10 = p10 >= 0 ? vb[(int64_t)p10 * row_stride] : 0.f;
-          const float v11 = p11 >= 0 ? vb[(int64_t)p11 * row_stride] : 0.f;
-          const float d00 = v00 * go, d01 = v01 * go, d10 = v10 * go, d11 = v11 * go;
-          const float w00 = hh * hw, w01 = hh * lw, w10 = lh * hw, w11 = lh * lw;
-          gw = w00 * d00 + w01 * d01 + w10 * d10 + w11 * d11;
-          gx = w * Wl * (-hh * d00 + hh * d01 - lh * d10 + lh * d11);
-          gy = w * Hl * (-hw * d00 - lw * d01 + hw * d10 + lw * d11);
-          const float wg = w * go;
-          if (tbl) {
-            if (p00 >= 0) wc_add(tags, acc, grad_value, (int)(key_b + (int64_t)p00 * H), ch, w00 * wg, leader);
-            if (p01 >= 0) wc_add(tags, acc, grad_value, (int)(key_b + (int64_t)p01 * H), ch, w01 * wg, leader);
-            if (p10 >= 0) wc_add(tags, acc, grad_value, (int)(key_b + (int64_t)p10 * H), ch, w10 * wg, leader);
-            if (p11 >= 0) wc_add(tags, acc, grad_value, (int)(key_b + (int64_t)p11 * H), ch, w11 * wg, leader);
-          } else {
-            float* gvb = grad_value + (int64_t)b * Nv * row_stride + h * kCh + ch;
-            if (p00 >= 0) unsafeAtomicAdd(gvb + (int64_t)p00 * row_stride, w00 * wg);
-            if (p01 >= 0) unsafeAtomicAdd(gvb + (int64_t)p01 * row_stride, w01 * wg);
-            if (p10 >= 0) unsafeAtomicAdd(gvb + (int64_t)p10 * row_stride, w10 * wg);
-            if (p11 >= 0) unsafeAtomicAdd(gvb + (int64_t)p11 * row_stride, w11 * wg);
-          }
-        }
-        gx = half_wave_sum(gx); gy = half_wave_sum(gy); gw = half_wave_sum(gw);
-        if (ch == 0) {
-          st_loc[(l * P + p) * 2] = gx;
-          st_loc[(l * P + p) * 2 + 1] = gy;
-          st_w[l * P + p] = gw;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int i = ch; i < LP * 2; i += kBLanes) grad_loc[item * LP * 2 + i] = st_loc[i];
-    for (int i = ch; i < LP; i += kBLanes) grad_w[item * LP + i] = st_w[i];
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-  // flush: one global atomic request per touched line
-  for (int sidx = grp; sidx < kSlots; sidx += kGroups) {
-    const int key = tags[sidx];
-    if (key >= 0) unsafeAtomicAdd(grad_value + (int64_t)key * kCh + ch, acc[sidx * kCh + ch]);
-  }
-}
-
 inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
   return B < 0 || Nv < 0 || H <= 0 || C != kCh || Nq < 0 || L <= 0 || P <= 0 || L * P > kMaxLP;
 }
@@ -373,16 +230,6 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        const float* attn_weight, const float* grad_out, float* grad_value,
                        float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
                        int Nq, int L, int P, void* stream) {
-  return vidar_msda_bwd_hint_f32(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                 grad_out, grad_value, grad_sampling_loc, grad_attn_weight, B, Nv, H,
-                                 C, Nq, L, P, 0, stream);
-}
-
-int vidar_msda_bwd_hint_f32(const float* value, const int64_t* spatial_shapes,
-                            const int64_t* level_start_index, const float* sampling_loc,
-                            const float* attn_weight, const float* grad_out, float* grad_value,
-                            float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H,
-                            int C, int Nq, int L, int P, int msda_grid_w, void* stream) {
   VIDAR_ENTER();
   if (msda_bad(B, Nv, H, C, Nq, L, P)) return VIDAR_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -393,23 +240,6 @@ int vidar_msda_bwd_hint_f32(const float* value, const int64_t* spatial_shapes,
   }
   const int64_t n_items = (int64_t)B * Nq * H;
   if (n_items == 0) return 0;
-  // write-combining variant whenever line keys fit 31 bits and heads split evenly
-  const bool wc_ok = (H % kHB == 0) && ((int64_t)B * Nv * H < (1ll << 31)) && Nq >= kQB;
-  if (wc_ok) {
-    // self-attention over the query grid itself? (single level whose map has exactly Nq cells)
-    int tile_w = 0;
-    if (L == 1 && msda_grid_w > 0 && (Nq % msda_grid_w) == 0 && Nv == Nq) tile_w = msda_grid_w;
-    int qblocks;
-    if (tile_w > 0) qblocks = ((tile_w + 7) / 8) * (((Nq / tile_w) + 7) / 8);
-    else qblocks = (Nq + kQB - 1) / kQB;
-    const int grid_wc = B * qblocks * (H / kHB);
-    const size_t lds_wc = sizeof(float) * (kSlots * kCh + kSlots + kGroups * L * P * 3);
-    hipLaunchKernelGGL(msda_bwd_wc_kernel, dim3(grid_wc), dim3(kThreads), lds_wc, s, value,
-                       spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
-                       grad_value, grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, tile_w,
-                       L > 1 ? 1 : 0, qblocks);
-    return vidar_last_error();
-  }
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
   const int grid = ((nblocks + 7) / 8) * 8;
   const size_t lds = sizeof(float) * kBItems * L * P * 3;

@@ -3,8 +3,6 @@ projects/mmdet3d_plugin/bevformer/modules/multi_scale_deformable_attn_function.p
 backed by vidar_msda_{fwd,bwd}_f32 (gfx950 HIP) instead of mmcv._ext."""
 from __future__ import annotations
 
-import math
-
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -41,12 +39,9 @@ def _msda_backward(value, shapes, lsi, loc, w, grad_out):
     gl = torch.empty_like(loc)
     gw = torch.empty_like(w)
     with TIMER.span(f"msda_bwd[L={L},P={P}]", msda_bwd_bytes(B, Nv, H, C, Nq, L, P)):
-        # locality hint (no effect on results): BEV self-attention samples its own square query grid
-        side = math.isqrt(Nq)
-        grid_w = side if (L == 1 and Nv == Nq and side * side == Nq) else 0
-        check(lib().vidar_msda_bwd_hint_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w),
-                                            ptr(grad_out), ptr(gv), ptr(gl), ptr(gw), B, Nv, H, C, Nq,
-                                            L, P, grid_w, stream_of(value)), "ms_deform_attn_backward")
+        check(lib().vidar_msda_bwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w),
+                                       ptr(grad_out), ptr(gv), ptr(gl), ptr(gw), B, Nv, H, C, Nq, L, P,
+                                       stream_of(value)), "ms_deform_attn_backward")
     return gv, gl, gw
 
 
