@@ -11,9 +11,10 @@
 //    *online* recurrence.  With T_k = exp(-csd_k) and W_k = T_k (d_{k+1}-d_k):
 //        pred_dist      = d_0 + sum_k W_k                (summation by parts)
 //        dd_dsigma[i]   = -dt_i * sum_{k>=i} W_k         (suffix sum)
-//    so pass A computes the total S = sum W_k and pass B re-marches the ray and
-//    emits dt_i * (P_i - S) with the running prefix P_i.  No per-ray arrays,
-//    no scratch, registers only.
+//    dvr.render re-marches the ray once the total S is known and scatters
+//    dl_dd * dt_i * (P_i - S); dvxlr.render marches ONCE, parks (W, dt) in its own
+//    output rows and finishes them with a coalesced wave-scan pass.  No per-ray
+//    arrays, no scratch, registers only.
 //  * The "consecutive duplicate voxel" merge of dvxlr (dvxlr.cu:366-373) is a
 //    one-slot pending sample that is either widened or committed.
 //  * The kernel owns the padding of the API-mandated [N,M,MAX_D(,3)] rows: the
@@ -132,7 +133,7 @@ __device__ __forceinline__ double march(const RayIn& r, const Vol& g, Sink& sink
   return len;
 }
 
-// Online integrator shared by every variant.  Emit::commit(k, x,y,z, d, dt, P_k)
+// Online integrator shared by every variant.  Emit::commit(k, x,y,z, d, dt, P_k, W_{k-1})
 // is called once per *final* sample k in order (P_k = prefix of W before k).
 template <int MODE, int MAXD, class Emit>
 struct Integrator {
@@ -152,14 +153,18 @@ struct Integrator {
 
   __device__ __forceinline__ void commit(int x, int y, int z, double d, double dt) {
     const double sg = (double)sig[((size_t)z * Y + y) * X + x];
+    double w_prev = 0.0;                       // W_{k-1} = T_{k-1} (d_k - d_{k-1})
     if (k == 0) {
       d0 = d;
     } else {
-      S += Tprev * (d - dprev);
+      w_prev = Tprev * (d - dprev);
+      S += w_prev;
     }
-    emit.commit(k, x, y, z, d, dt, S);
+    emit.commit(k, x, y, z, d, dt, S, w_prev);
     csd = (k == 0) ? sg * dt : csd + sg * dt;
-    Tprev = exp(-csd);
+    // the transmittance only scales value outputs (1e-7 relative is plenty for fp32 results);
+    // csd itself and every traversal quantity stay fp64
+    Tprev = (double)expf((float)(-csd));
     dprev = d;
     ++k;
   }
@@ -190,7 +195,7 @@ struct Integrator {
 };
 
 struct NoEmit {
-  __device__ __forceinline__ void commit(int, int, int, int, double, double, double) {}
+  __device__ __forceinline__ void commit(int, int, int, int, double, double, double, double) {}
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -227,7 +232,8 @@ struct GradScatter {
   float* __restrict__ grad;  // grad_sigma[n][ts] slice
   int Y, X;
   double S_total, dl_dd;
-  __device__ __forceinline__ void commit(int, int x, int y, int z, double, double dt, double P) {
+  __device__ __forceinline__ void commit(int, int x, int y, int z, double, double dt, double P,
+                                         double) {
     const double g = dl_dd * (dt * (P - S_total));
     if (g != 0.0) unsafeAtomicAdd(grad + ((size_t)z * Y + y) * X + x, (float)g);
   }
@@ -270,43 +276,27 @@ __global__ __launch_bounds__(kWave) void dvr_render_kernel(
 // ----------------------------------------------------------------------------------------------
 // dvxlr.render / dvxlr_v2.render_v2
 // ----------------------------------------------------------------------------------------------
-template <bool V2>
-struct RowWriter {
-  float* __restrict__ dd;    // dd_dsigma[n][c]
-  float* __restrict__ idx;   // indices[n][c]
-  float* __restrict__ rp;    // ray_pred[n][c]     (V2)
-  float* __restrict__ ind;   // indicator[n][c]    (V2)
-  const float* __restrict__ regul;  // sigma_regul[n][ts] (V2)
-  int Y, X;
-  double S_total, true_len;
-  bool reached = false;
-  __device__ __forceinline__ void commit(int k, int x, int y, int z, double d, double dt, double P) {
-    dd[k] = (float)(dt * (P - S_total));
-    idx[3 * k + 0] = (float)z;
-    idx[3 * k + 1] = (float)y;
+// Single march.  While a lane walks its ray it parks, inside the ray's own output rows,
+//   dd_row[k-1]   <- W_{k-1}            (fp32)          idx_row[3k+0] <- dt_k (fp32)
+//   idx_row[3k+1] <- z*Y + y (exact)                    idx_row[3k+2] <- x
+// and afterwards the whole wave revisits the 64 rows it owns with coalesced accesses: a reverse
+// wave scan turns W into the suffix sums R_k, dd_dsigma[k] = -dt_k R_k, (z, y) are unpacked, the
+// v2 extras are gathered and the tails are padded.  One traversal, one exp per sample, no scratch.
+struct RowStager {
+  float* __restrict__ dd;
+  float* __restrict__ idx;
+  int Y;
+  double true_len;
+  int k_surface = -1;
+  __device__ __forceinline__ void commit(int k, int x, int y, int z, double d, double dt, double,
+                                         double w_prev) {
+    if (k > 0) dd[k - 1] = (float)w_prev;
+    idx[3 * k + 0] = (float)dt;
+    idx[3 * k + 1] = (float)(z * Y + y);
     idx[3 * k + 2] = (float)x;
-    if (V2) {
-      float flag = 0.f;
-      if (!reached && d >= true_len) { flag = 1.f; reached = true; }
-      ind[k] = flag;
-      rp[k] = regul[((size_t)z * Y + y) * X + x];
-    }
+    if (k_surface < 0 && d >= true_len) k_surface = k;    // dvxlr_v2.cu:408-424
   }
 };
-
-// whole wave pads rows [cnt, MAXD) of the 64 rays it owns with `fill`
-__device__ __forceinline__ void pad_rows(float* __restrict__ base, size_t row_elems, int per, int cnt,
-                                         int c0, int M, float fill) {
-  const int lane = threadIdx.x;
-  for (int r = 0; r < kWave; ++r) {
-    const int cr = c0 + r;
-    if (cr >= M) break;
-    const int k = __shfl(cnt, r, kWave);
-    float* row = base + (size_t)cr * row_elems;
-    const int begin = k * per, end = (int)row_elems;
-    for (int i = begin + lane; i < end; i += kWave) row[i] = fill;
-  }
-}
 
 template <bool V2>
 __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
@@ -315,44 +305,84 @@ __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
     const float* __restrict__ tindex, float* __restrict__ pred_dist, float* __restrict__ gt_dist,
     float* __restrict__ dd_dsigma, float* __restrict__ indices, float* __restrict__ ray_pred,
     float* __restrict__ indicator, int M, Vol g) {
+  constexpr int L = kDvxlrMaxD;
   const int n = blockIdx.y;
   const int c0 = blockIdx.x * kWave;
-  const int c = c0 + threadIdx.x;
-  int count = 0;
+  const int lane = threadIdx.x;
+  const int c = c0 + lane;
   const size_t rowbase = (size_t)n * M;
+  const size_t vol = (size_t)g.Z * g.Y * g.X;
+  int count = 0, ksurf = -1, ts = 0;
   if (c < M) {
     float pred = -1.f, gt = -1.f;
     const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
+    ts = r.ts;
     if (r.valid) {
-      const size_t vol = (size_t)g.Z * g.Y * g.X;
-      const size_t slice = ((size_t)n * g.T + r.ts) * vol;
-      NoEmit ne;
-      Integrator<kRoundedMerged, kDvxlrMaxD, NoEmit> a(sigma + slice, g.Y, g.X, ne);
+      RowStager st;
+      st.dd = dd_dsigma + (rowbase + c) * L;
+      st.idx = indices + (rowbase + c) * L * 3;
+      st.Y = g.Y;
+      {
+        const double rx = r.xe - r.xo, ry = r.ye - r.yo, rz = r.ze - r.zo;
+        st.true_len = sqrt(rx * rx + ry * ry + rz * rz);
+      }
+      Integrator<kRoundedMerged, kDvxlrMaxD, RowStager> a(sigma + ((size_t)n * g.T + r.ts) * vol, g.Y,
+                                                          g.X, st);
       const double len = march<kRoundedMerged>(r, g, a);
-      if (a.k > 0) {
+      count = a.k;
+      ksurf = st.k_surface;
+      if (count > 0) {
         pred = (float)(a.d0 + a.S);
         gt = (float)fmin(len, a.dprev);
-        RowWriter<V2> w;
-        w.dd = dd_dsigma + (rowbase + c) * kDvxlrMaxD;
-        w.idx = indices + (rowbase + c) * kDvxlrMaxD * 3;
-        w.rp = V2 ? ray_pred + (rowbase + c) * kDvxlrMaxD : nullptr;
-        w.ind = V2 ? indicator + (rowbase + c) * kDvxlrMaxD : nullptr;
-        w.regul = V2 ? sigma_regul + slice : nullptr;
-        w.Y = g.Y; w.X = g.X; w.S_total = a.S; w.true_len = len;
-        Integrator<kRoundedMerged, kDvxlrMaxD, RowWriter<V2>> b(sigma + slice, g.Y, g.X, w);
-        march<kRoundedMerged>(r, g, b);
-        count = b.k;
       }
     }
     pred_dist[rowbase + c] = pred;
     gt_dist[rowbase + c] = gt;
   }
-  // tails (and whole rows of rays that never met the volume)
-  pad_rows(dd_dsigma + rowbase * kDvxlrMaxD, kDvxlrMaxD, 1, count, c0, M, 0.f);
-  pad_rows(indices + rowbase * kDvxlrMaxD * 3, (size_t)kDvxlrMaxD * 3, 3, count, c0, M, 0.f);
-  if (V2) {
-    pad_rows(ray_pred + rowbase * kDvxlrMaxD, kDvxlrMaxD, 1, count, c0, M, 0.f);
-    pad_rows(indicator + rowbase * kDvxlrMaxD, kDvxlrMaxD, 1, count, c0, M, -1.f);
+  __threadfence_block();      // the staged rows were written by single lanes, now every lane reads them
+
+  for (int r = 0; r < kWave; ++r) {
+    const int cr = c0 + r;
+    if (cr >= M) break;
+    const int cnt = __shfl(count, r, kWave);
+    float* ddr = dd_dsigma + (rowbase + cr) * L;
+    float* idr = indices + (rowbase + cr) * L * 3;
+    float* rpr = V2 ? ray_pred + (rowbase + cr) * L : nullptr;
+    float* inr = V2 ? indicator + (rowbase + cr) * L : nullptr;
+    const int ks = __shfl(ksurf, r, kWave);
+    const int tsr = __shfl(ts, r, kWave);
+    const float* reg = V2 ? sigma_regul + ((size_t)n * g.T + tsr) * vol : nullptr;
+    double carry = 0.0;
+    for (int base = cnt > 0 ? ((cnt - 1) / kWave) * kWave : -1; base >= 0; base -= kWave) {
+      const int k = base + lane;
+      double sfx = (k < cnt - 1) ? (double)ddr[k] : 0.0;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const double t = __shfl_down(sfx, off, kWave);
+        if (lane + off < kWave) sfx += t;
+      }
+      const double R = sfx + carry;
+      carry += __shfl(sfx, 0, kWave);
+      if (k < cnt) {
+        const float dtk = idr[3 * k + 0];
+        const int zy = (int)idr[3 * k + 1];
+        const int z = zy / g.Y, y = zy - z * g.Y;
+        ddr[k] = (float)(-(double)dtk * R);
+        idr[3 * k + 0] = (float)z;
+        idr[3 * k + 1] = (float)y;
+        if (V2) {
+          const int x = (int)idr[3 * k + 2];
+          rpr[k] = reg[((size_t)z * g.Y + y) * g.X + x];
+          inr[k] = (k == ks) ? 1.f : 0.f;
+        }
+      }
+    }
+    // pad the tails (whole rows for rays that never met the volume)
+    for (int i = cnt + lane; i < L; i += kWave) ddr[i] = 0.f;
+    for (int i = cnt * 3 + lane; i < L * 3; i += kWave) idr[i] = 0.f;
+    if (V2) {
+      for (int i = cnt + lane; i < L; i += kWave) { rpr[i] = 0.f; inr[i] = -1.f; }
+    }
   }
 }
 
