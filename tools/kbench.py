@@ -33,6 +33,13 @@ def report(name, ms, nbytes=None, **kw):
 
 
 def bench_dvr(which):
+    buf = torch.empty(2478800000 // 4, device="cuda")
+    ms = timeit(lambda: buf.zero_())
+    report("device fill 2.48 GB (write ceiling)", ms, buf.numel() * 4)
+    src = torch.empty_like(buf)
+    ms = timeit(lambda: buf.copy_(src))
+    report("device copy 2.48 GB (read+write bytes)", ms, buf.numel() * 8)
+    del buf, src
     from vidar_amd.synthetic import ray_set
     from vidar_amd.third_lib import dvr, dvxlr, dvxlr_v2
     t = lambda a: torch.from_numpy(a).cuda()

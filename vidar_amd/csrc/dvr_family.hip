@@ -298,6 +298,21 @@ struct RowStager {
   }
 };
 
+// whole-wave fill of `n` floats starting at `p` (8-byte aligned): 16-byte aligned float4 stream so
+// that HBM sees full 128-byte line writes (no write-allocate reads), scalar head/tail.
+__device__ __forceinline__ void wave_fill(float* __restrict__ p, size_t n, float v) {
+  const int lane = threadIdx.x;
+  size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / sizeof(float);
+  if (head > n) head = n;
+  if ((size_t)lane < head) p[lane] = v;
+  float4* q = reinterpret_cast<float4*>(p + head);
+  const size_t n4 = (n - head) / 4;
+  const float4 v4 = make_float4(v, v, v, v);
+  for (size_t i = lane; i < n4; i += kWave) q[i] = v4;
+  const size_t done = head + n4 * 4;
+  if (done + lane < n) p[done + lane] = v;
+}
+
 template <bool V2>
 __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
     const float* __restrict__ sigma, const float* __restrict__ sigma_regul,
@@ -313,6 +328,17 @@ __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
   const size_t rowbase = (size_t)n * M;
   const size_t vol = (size_t)g.Z * g.Y * g.X;
   int count = 0, ksurf = -1, ts = 0;
+  // the 64 rows this wave owns are contiguous: pad them first with one aligned stream; the live
+  // prefixes written afterwards land on lines that are still in L2
+  {
+    const size_t rows = (size_t)min(kWave, M - c0);
+    wave_fill(dd_dsigma + (rowbase + c0) * L, rows * L, 0.f);
+    wave_fill(indices + (rowbase + c0) * L * 3, rows * L * 3, 0.f);
+    if (V2) {
+      wave_fill(ray_pred + (rowbase + c0) * L, rows * L, 0.f);
+      wave_fill(indicator + (rowbase + c0) * L, rows * L, -1.f);
+    }
+  }
   if (c < M) {
     float pred = -1.f, gt = -1.f;
     const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
@@ -376,12 +402,6 @@ __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
           inr[k] = (k == ks) ? 1.f : 0.f;
         }
       }
-    }
-    // pad the tails (whole rows for rays that never met the volume)
-    for (int i = cnt + lane; i < L; i += kWave) ddr[i] = 0.f;
-    for (int i = cnt * 3 + lane; i < L * 3; i += kWave) idr[i] = 0.f;
-    if (V2) {
-      for (int i = cnt + lane; i < L; i += kWave) { rpr[i] = 0.f; inr[i] = -1.f; }
     }
   }
 }
