@@ -367,28 +367,34 @@ __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
   }
   __threadfence_block();      // the staged rows were written by single lanes, now every lane reads them
 
-  for (int r = 0; r < kWave; ++r) {
+  // fix-up: four rays at a time, 16 lanes each (the per-ray chain "load W -> scan -> store" is
+  // latency bound, so independent rays run side by side)
+  constexpr int kSub = 16;
+  const int grp = lane / kSub, gl = lane % kSub, lead = lane & ~(kSub - 1);
+  for (int rq = 0; rq < kWave / (kWave / kSub); ++rq) {
+    const int r = rq * (kWave / kSub) + grp;
     const int cr = c0 + r;
-    if (cr >= M) break;
-    const int cnt = __shfl(count, r, kWave);
-    float* ddr = dd_dsigma + (rowbase + cr) * L;
-    float* idr = indices + (rowbase + cr) * L * 3;
-    float* rpr = V2 ? ray_pred + (rowbase + cr) * L : nullptr;
-    float* inr = V2 ? indicator + (rowbase + cr) * L : nullptr;
+    const int cnt_r = __shfl(count, r, kWave);       // unconditional: every lane takes part
+    const int cnt = (cr < M) ? cnt_r : 0;
     const int ks = __shfl(ksurf, r, kWave);
     const int tsr = __shfl(ts, r, kWave);
+    const size_t row = rowbase + (cr < M ? cr : c0);
+    float* ddr = dd_dsigma + row * L;
+    float* idr = indices + row * L * 3;
+    float* rpr = V2 ? ray_pred + row * L : nullptr;
+    float* inr = V2 ? indicator + row * L : nullptr;
     const float* reg = V2 ? sigma_regul + ((size_t)n * g.T + tsr) * vol : nullptr;
     double carry = 0.0;
-    for (int base = cnt > 0 ? ((cnt - 1) / kWave) * kWave : -1; base >= 0; base -= kWave) {
-      const int k = base + lane;
+    for (int base = cnt > 0 ? ((cnt - 1) / kSub) * kSub : -1; base >= 0; base -= kSub) {
+      const int k = base + gl;
       double sfx = (k < cnt - 1) ? (double)ddr[k] : 0.0;
 #pragma unroll
-      for (int off = 1; off < kWave; off <<= 1) {
+      for (int off = 1; off < kSub; off <<= 1) {
         const double t = __shfl_down(sfx, off, kWave);
-        if (lane + off < kWave) sfx += t;
+        if (gl + off < kSub) sfx += t;
       }
       const double R = sfx + carry;
-      carry += __shfl(sfx, 0, kWave);
+      carry += __shfl(sfx, lead, kWave);
       if (k < cnt) {
         const float dtk = idr[3 * k + 0];
         const int zy = (int)idr[3 * k + 1];
