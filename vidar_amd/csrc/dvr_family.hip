@@ -277,23 +277,22 @@ __global__ __launch_bounds__(kWave) void dvr_render_kernel(
 // dvxlr.render / dvxlr_v2.render_v2
 // ----------------------------------------------------------------------------------------------
 // Single march.  While a lane walks its ray it parks, inside the ray's own output rows,
-//   dd_row[k-1]   <- W_{k-1}            (fp32)          idx_row[3k+0] <- dt_k (fp32)
-//   idx_row[3k+1] <- z*Y + y (exact)                    idx_row[3k+2] <- x
+//   dd_row[k-1]   <- W_{k-1} (fp32)     idx_row[3k+0] <- dt_k (fp32)
+//   idx_row[3k+1] <- linear voxel id (z*Y + y)*X + x, exact in fp32 below 2^24 voxels per slice
 // and afterwards the whole wave revisits the 64 rows it owns with coalesced accesses: a reverse
 // wave scan turns W into the suffix sums R_k, dd_dsigma[k] = -dt_k R_k, (z, y) are unpacked, the
 // v2 extras are gathered and the tails are padded.  One traversal, one exp per sample, no scratch.
 struct RowStager {
   float* __restrict__ dd;
   float* __restrict__ idx;
-  int Y;
+  int Y, X;
   double true_len;
   int k_surface = -1;
   __device__ __forceinline__ void commit(int k, int x, int y, int z, double d, double dt, double,
                                          double w_prev) {
     if (k > 0) dd[k - 1] = (float)w_prev;
     idx[3 * k + 0] = (float)dt;
-    idx[3 * k + 1] = (float)(z * Y + y);
-    idx[3 * k + 2] = (float)x;
+    idx[3 * k + 1] = (float)((z * Y + y) * X + x);
     if (k_surface < 0 && d >= true_len) k_surface = k;    // dvxlr_v2.cu:408-424
   }
 };
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
       RowStager st;
       st.dd = dd_dsigma + (rowbase + c) * L;
       st.idx = indices + (rowbase + c) * L * 3;
-      st.Y = g.Y;
+      st.Y = g.Y; st.X = g.X;
       {
         const double rx = r.xe - r.xo, ry = r.ye - r.yo, rz = r.ze - r.zo;
         st.true_len = sqrt(rx * rx + ry * ry + rz * rz);
@@ -371,14 +370,15 @@ __global__ __launch_bounds__(kWave) void dvxlr_render_kernel(
       carry += __shfl(sfx, lead, kWave);
       if (k < cnt) {
         const float dtk = idr[3 * k + 0];
-        const int zy = (int)idr[3 * k + 1];
+        const int vid = (int)idr[3 * k + 1];
+        const int zy = vid / g.X, x = vid - zy * g.X;
         const int z = zy / g.Y, y = zy - z * g.Y;
         ddr[k] = (float)(-(double)dtk * R);
         idr[3 * k + 0] = (float)z;
         idr[3 * k + 1] = (float)y;
+        idr[3 * k + 2] = (float)x;
         if (V2) {
-          const int x = (int)idr[3 * k + 2];
-          rpr[k] = reg[((size_t)z * g.Y + y) * g.X + x];
+          rpr[k] = reg[vid];
           inr[k] = (k == ks) ? 1.f : 0.f;
         }
       }
@@ -513,7 +513,7 @@ int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float*
                            float* indices, int N, int M, int T, int TO, int Z, int Y, int X,
                            void* stream) {
   VIDAR_ENTER();
-  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0) return VIDAR_ERR_BAD_ARG;
+  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0 || (size_t)Z * Y * X >= (1u << 24)) return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
   dim3 grid((M + kWave - 1) / kWave, N);
@@ -535,7 +535,7 @@ int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float
                             float* indicator, int N, int M, int T, int TO, int Z, int Y, int X,
                             void* stream) {
   VIDAR_ENTER();
-  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0) return VIDAR_ERR_BAD_ARG;
+  if (bad_dims(N, M, T, Z, Y, X) || TO <= 0 || (size_t)Z * Y * X >= (1u << 24)) return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
   dim3 grid((M + kWave - 1) / kWave, N);
