@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="vidar_1_8_nusc_1future")
     ap.add_argument("--rays-per-frame", type=int, default=30000)
+    ap.add_argument("--no-backbone", action="store_true",
+                    help="feed FPN pyramids instead of images (hot path of SURVEY 8a only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 16))
@@ -45,7 +47,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(config, threads):
+def synthetic_images(seed, T, num_cams, hw, device, scale=1):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(1, T, num_cams, 3, hw[0] // scale, hw[1] // scale, generator=g).to(device)
+
+
+def cpu_baseline(config, threads, with_backbone=True):
     """The oracle port of the same training step on host cores, bounded sample: BEV 50x50 (1/16 of
     the 40 000 queries), FPN pyramid of a quarter-resolution input, rays_per_frame/16 GT rays."""
     from oracle import cpu_ops
@@ -53,15 +60,24 @@ def cpu_baseline(config, threads):
     from vidar_amd.configs import get_config
     from vidar_amd.synthetic import fpn_features, make_sample
     torch.set_num_threads(threads)
-    cfg = get_config(config, bev_h=50, bev_w=50)
+    cfg = get_config(config, bev_h=50, bev_w=50, with_backbone=with_backbone)
     torch.manual_seed(0); np.random.seed(0)
     model = T.build_model(cfg).train()
     opt = T.build_optimizer(model)
     metas, gt = make_sample(0, rays_per_frame=30000 // 16, future_frames=cfg["future_frames"],
                             num_cams=cfg["num_cams"], img_hw=cfg["img_hw"])
-    shapes = [((h + 3) // 4, (w + 3) // 4) for h, w in cfg["fpn_shapes"]]
-    feats = fpn_features(0, 5, num_cams=cfg["num_cams"], shapes=shapes)
-    batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt)], img_feats=feats)
+    if with_backbone:
+        qhw = (cfg["img_hw"][0] // 4, cfg["img_hw"][1] // 4)
+        for m in metas:
+            m["img_shape"] = [(qhw[0], qhw[1], 3)] * cfg["num_cams"]
+            k = np.diag([0.25, 0.25, 1.0, 1.0])
+            m["lidar2img"] = [k @ a for a in m["lidar2img"]]
+        batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt)],
+                     img=synthetic_images(0, 5, cfg["num_cams"], cfg["img_hw"], "cpu", scale=4))
+    else:
+        shapes = [((h + 3) // 4, (w + 3) // 4) for h, w in cfg["fpn_shapes"]]
+        feats = fpn_features(0, 5, num_cams=cfg["num_cams"], shapes=shapes)
+        batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt)], img_feats=feats)
     with cpu_ops.patched():
         T.train_step(model, opt, batch)             # warm-up
         t0 = time.perf_counter()
@@ -71,7 +87,8 @@ def cpu_baseline(config, threads):
         dt = (time.perf_counter() - t0) / n
     scale = 16.0
     return dict(value=1.0 / (dt * scale), unit="samples/s", cores=threads, kind="port",
-                sample=f"oracle port of the step at BEV 50x50, FPN of a 1/4-res input, 1875 rays/frame: "
+                sample=f"oracle port of the step ({'with' if with_backbone else 'without'} backbone) at BEV "
+                       f"50x50, 1/4-res images (1/16 of the pixels), 1875 rays/frame: "
                        f"{dt:.2f} s/step measured, x{scale:.0f} work -> full-size estimate")
 
 
@@ -79,7 +96,7 @@ def cpu_baseline_subprocess(args):
     """Run the CPU leg in a child with a hard wall-clock limit so it can never stall the bench."""
     import subprocess
     cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--config", args.config,
-           "--cpu-threads", str(args.cpu_threads)]
+           "--cpu-threads", str(args.cpu_threads)] + (["--no-backbone"] if args.no_backbone else [])
     env = dict(os.environ, OMP_NUM_THREADS=str(args.cpu_threads), MKL_NUM_THREADS=str(args.cpu_threads))
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout, env=env)
@@ -95,7 +112,7 @@ def cpu_baseline_subprocess(args):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.config, args.cpu_threads)), flush=True)
+        print(json.dumps(cpu_baseline(args.config, args.cpu_threads, not args.no_backbone)), flush=True)
         return
     from vidar_amd import train as T
     from vidar_amd._lib import TIMER
@@ -107,7 +124,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = get_config(args.config)
+    cfg = get_config(args.config, with_backbone=not args.no_backbone)
     torch.manual_seed(1234)                      # identical initial weights on every rank
     np.random.seed(1000 + rank)
     model = T.build_model(cfg).to(dev).train()
@@ -116,9 +133,13 @@ def main():
     metas, gt = make_sample(seed=100 + rank, queue_length=cfg["queue_length"],
                             future_frames=cfg["future_frames"], rays_per_frame=args.rays_per_frame,
                             num_cams=cfg["num_cams"], img_hw=cfg["img_hw"])
-    feats = fpn_features(200 + rank, cfg["queue_length"] + 1, num_cams=cfg["num_cams"],
-                         shapes=cfg["fpn_shapes"], device=dev)
-    batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)], img_feats=feats)
+    if args.no_backbone:
+        feats = fpn_features(200 + rank, cfg["queue_length"] + 1, num_cams=cfg["num_cams"],
+                             shapes=cfg["fpn_shapes"], device=dev)
+        batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)], img_feats=feats)
+    else:
+        imgs = synthetic_images(200 + rank, cfg["queue_length"] + 1, cfg["num_cams"], cfg["img_hw"], dev)
+        batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)], img=imgs)
 
     def sync():
         if world > 1:
@@ -156,11 +177,11 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config} hot path: FPN features [1,5,{cfg['num_cams']},256,"
-                                   f"{cfg['fpn_shapes'][0][0]}x{cfg['fpn_shapes'][0][1]}..] -> 5x BEV encode "
-                                   f"(6 layers TSA+SCA, LatentRendering, bev 200x200) -> head -> ray CE + "
-                                   f"gumbel render + chamfer -> backward -> AdamW; image backbone not included "
-                                   f"(SURVEY §8f row 1)",
+            "config": {"workload": (f"{args.config}: images [1,5,{cfg['num_cams']},3,{cfg['img_hw'][0]}x"
+                                    f"{cfg['img_hw'][1]}] -> ResNet101-DCNv2 + FPN -> " if not args.no_backbone
+                                    else f"{args.config} (no image backbone): FPN pyramids -> ")
+                                   + "5x BEV encode (6 layers TSA+SCA, LatentRendering, bev 200x200) -> head -> "
+                                     "ray CE + gumbel render + chamfer -> backward -> clip -> AdamW",
                        "global_batch": world, "rays_per_frame": args.rays_per_frame,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -188,6 +188,22 @@ int vidar_ray_argmax_f32(const float* sigma, const float* origin, const float* p
                          const float* tindex, float* pred_dist, float* gt_dist, int F, int R, int Z,
                          int Y, int X, int K, float step, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Modulated deformable convolution v2 (backbone, "next" row SURVEY 8f-1).  Replaces the sampling
+ * kernels of mmcv.ops.ModulatedDeformConv2dPack (mmcv-full 1.4.0, third party); the convolution
+ * itself is a GEMM of weight [Cout, C*kh*kw] with the column matrix built here.
+ *   x [N,C,H,W], offset [N,2*kh*kw,Ho,Wo] ((dy,dx) per tap), mask [N,kh*kw,Ho,Wo],
+ *   cols / grad_cols [N, C*kh*kw, Ho*Wo].  deform_groups == 1.
+ * col2im: grad_x zeroed by the call then accumulated with atomics; grad_offset / grad_mask written.
+ * ------------------------------------------------------------------------- */
+int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
+                         int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                         int dil, void* stream);
+int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* offset,
+                         const float* mask, float* grad_x, float* grad_offset, float* grad_mask,
+                         int N, int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride,
+                         int pad, int dil, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ import contextlib
 
 import torch
 
+from . import dcn as DCN
 from . import head as H
 from . import latent_render as LR
 from . import msda as M
@@ -52,7 +53,7 @@ def _gumbel_noise(R, K=512, device="cpu", generator=None):
 
 @contextlib.contextmanager
 def patched():
-    from vidar_amd.plugin import losses
+    from vidar_amd.plugin import backbones, losses
     from vidar_amd.plugin.dense_heads import ray_ops
     from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
     from vidar_amd.plugin.modules.ray_operations import latent_rendering as L
@@ -61,7 +62,8 @@ def patched():
              (L, "latent_render_gather", L.latent_render_gather),
              (ray_ops, "ray_ce", ray_ops.ray_ce), (ray_ops, "ray_gumbel", ray_ops.ray_gumbel),
              (ray_ops, "ray_argmax", ray_ops.ray_argmax), (ray_ops, "gumbel_noise", ray_ops.gumbel_noise),
-             (losses, "knn_points", losses.knn_points)]
+             (losses, "knn_points", losses.knn_points),
+             (backbones, "modulated_deform_conv2d", backbones.modulated_deform_conv2d)]
     try:
         F.MultiScaleDeformableAttnFunction_fp32.apply = staticmethod(_msda_apply)
         L.latent_render_path_prob = lambda occ, n, s, act="sigmoid": LR.path_prob(occ, n, s, act)
@@ -69,6 +71,7 @@ def patched():
         ray_ops.ray_ce, ray_ops.ray_gumbel, ray_ops.ray_argmax = _ray_ce, _ray_gumbel, _ray_argmax
         ray_ops.gumbel_noise = _gumbel_noise
         losses.knn_points = _knn_points
+        backbones.modulated_deform_conv2d = DCN.modulated_deform_conv2d
         yield
     finally:
         for obj, name, val in saved:

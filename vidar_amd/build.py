@@ -29,6 +29,7 @@ COMMON = [
 PER_FILE: dict[str, list[str]] = {
     # pure fp32 interpolation arithmetic, tolerance-checked: let the compiler fuse multiply-adds
     "msda.hip": ["-ffp-contract=fast"],
+    "dcn.hip": ["-ffp-contract=fast"],
 }
 
 

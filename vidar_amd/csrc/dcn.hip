@@ -1,0 +1,181 @@
+// Modulated deformable convolution v2 (DCNv2) sampling kernels for gfx950.
+//
+// Replaces mmcv.ops.ModulatedDeformConv2dPack's CUDA kernels (mmcv-full 1.4.0, third party, NOT
+// vendored in the reference) used by the ResNet101 backbone of every ViDAR config
+// (`dcn=dict(type='DCNv2', deform_groups=1, fallback_on_stride=False)`,
+//  projects/configs/vidar_pretrain/nusc_1_8_subset/vidar_1_8_nusc_1future.py:96-97).
+// The convolution itself stays a GEMM (weight [Cout, Cin*kh*kw] x columns, hipBLASLt / MFMA);
+// these kernels build / differentiate the deformable column matrix:
+//   cols[n, (c*K + t), p] = mask[n,t,p] * bilinear(x[n,c], p_y*s - pad + i*dil + off[n,2t,p],
+//                                                          p_x*s - pad + j*dil + off[n,2t+1,p])
+// with zero padding (a sample counts iff -1 < h < H and -1 < w < W; each corner zero outside).
+// Layouts: x [N,C,H,W], offset [N,2K,Ho,Wo] ((dy,dx) interleaved per tap), mask [N,K,Ho,Wo],
+// cols [N, C*K, Ho*Wo] -- lanes run over output pixels so column writes, offset/mask reads and
+// (for small offsets) input reads are coalesced; the backward scatter therefore puts neighbouring
+// lanes on the same 128-byte lines (atomics cost per instruction x line, see msda.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vidar_hip.h"
+#include "vidar_common.h"
+
+namespace {
+
+struct Conv {
+  int C, H, W, Ho, Wo, kh, kw, stride, pad, dil;
+};
+
+struct Bil {
+  int h0, w0;
+  float lh, lw;
+  bool in, t, b, l, r;
+};
+
+__device__ __forceinline__ Bil bil(float h, float w, int H, int W) {
+  Bil q;
+  q.in = h > -1.f && w > -1.f && h < H && w < W;
+  q.h0 = (int)floorf(h); q.w0 = (int)floorf(w);
+  q.lh = h - q.h0; q.lw = w - q.w0;
+  q.t = q.h0 >= 0; q.b = q.h0 + 1 <= H - 1; q.l = q.w0 >= 0; q.r = q.w0 + 1 <= W - 1;
+  return q;
+}
+
+__device__ __forceinline__ float sample(const float* __restrict__ im, const Bil& q, int W) {
+  if (!q.in) return 0.f;
+  const float v1 = (q.t && q.l) ? im[q.h0 * W + q.w0] : 0.f;
+  const float v2 = (q.t && q.r) ? im[q.h0 * W + q.w0 + 1] : 0.f;
+  const float v3 = (q.b && q.l) ? im[(q.h0 + 1) * W + q.w0] : 0.f;
+  const float v4 = (q.b && q.r) ? im[(q.h0 + 1) * W + q.w0 + 1] : 0.f;
+  const float hh = 1.f - q.lh, hw = 1.f - q.lw;
+  return hh * hw * v1 + hh * q.lw * v2 + q.lh * hw * v3 + q.lh * q.lw * v4;
+}
+
+// grid: (ceil(P/256), C, N)
+__global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ offset,
+                                                         const float* __restrict__ mask,
+                                                         float* __restrict__ cols, Conv g) {
+  const int P = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int py = p / g.Wo, px = p % g.Wo;
+  const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
+  const float* off = offset + (size_t)n * 2 * K * P + p;
+  const float* mk = mask + (size_t)n * K * P + p;
+  float* out = cols + ((size_t)n * g.C + c) * K * P + p;
+  for (int t = 0; t < K; ++t) {
+    const int i = t / g.kw, j = t % g.kw;
+    const float h = py * g.stride - g.pad + i * g.dil + off[(size_t)(2 * t) * P];
+    const float w = px * g.stride - g.pad + j * g.dil + off[(size_t)(2 * t + 1) * P];
+    out[(size_t)t * P] = sample(im, bil(h, w, g.H, g.W), g.W) * mk[(size_t)t * P];
+  }
+}
+
+// grad wrt input: scatter grad_cols * mask * corner weights (atomics); grid as im2col
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ grad_cols,
+                                                         const float* __restrict__ offset,
+                                                         const float* __restrict__ mask,
+                                                         float* __restrict__ grad_x, Conv g) {
+  const int P = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int py = p / g.Wo, px = p % g.Wo;
+  float* gim = grad_x + ((size_t)n * g.C + c) * g.H * g.W;
+  const float* off = offset + (size_t)n * 2 * K * P + p;
+  const float* mk = mask + (size_t)n * K * P + p;
+  const float* gc = grad_cols + ((size_t)n * g.C + c) * K * P + p;
+  for (int t = 0; t < K; ++t) {
+    const int i = t / g.kw, j = t % g.kw;
+    const float h = py * g.stride - g.pad + i * g.dil + off[(size_t)(2 * t) * P];
+    const float w = px * g.stride - g.pad + j * g.dil + off[(size_t)(2 * t + 1) * P];
+    const Bil q = bil(h, w, g.H, g.W);
+    if (!q.in) continue;
+    const float gv = gc[(size_t)t * P] * mk[(size_t)t * P];
+    if (gv == 0.f) continue;
+    const float hh = 1.f - q.lh, hw = 1.f - q.lw;
+    if (q.t && q.l) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0, hh * hw * gv);
+    if (q.t && q.r) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0 + 1, hh * q.lw * gv);
+    if (q.b && q.l) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0, q.lh * hw * gv);
+    if (q.b && q.r) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0 + 1, q.lh * q.lw * gv);
+  }
+}
+
+// grad wrt offset and mask: thread per (n, tap, pixel), loop over channels (no atomics)
+// grid: (ceil(P/256), K, N)
+__global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(
+    const float* __restrict__ grad_cols, const float* __restrict__ x,
+    const float* __restrict__ offset, const float* __restrict__ mask,
+    float* __restrict__ grad_offset, float* __restrict__ grad_mask, Conv g) {
+  const int P = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int t = blockIdx.y, n = blockIdx.z;
+  const int py = p / g.Wo, px = p % g.Wo;
+  const int i = t / g.kw, j = t % g.kw;
+  const size_t o = ((size_t)n * 2 * K + 2 * t) * P + p;
+  const float h = py * g.stride - g.pad + i * g.dil + offset[o];
+  const float w = px * g.stride - g.pad + j * g.dil + offset[o + P];
+  const float m = mask[((size_t)n * K + t) * P + p];
+  const Bil q = bil(h, w, g.H, g.W);
+  float gh = 0.f, gw = 0.f, gm = 0.f;
+  if (q.in) {
+    const float hh = 1.f - q.lh, hw = 1.f - q.lw;
+    for (int c = 0; c < g.C; ++c) {
+      const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
+      const float gc = grad_cols[(((size_t)n * g.C + c) * K + t) * P + p];
+      const float v1 = (q.t && q.l) ? im[q.h0 * g.W + q.w0] : 0.f;
+      const float v2 = (q.t && q.r) ? im[q.h0 * g.W + q.w0 + 1] : 0.f;
+      const float v3 = (q.b && q.l) ? im[(q.h0 + 1) * g.W + q.w0] : 0.f;
+      const float v4 = (q.b && q.r) ? im[(q.h0 + 1) * g.W + q.w0 + 1] : 0.f;
+      gm += gc * (hh * hw * v1 + hh * q.lw * v2 + q.lh * hw * v3 + q.lh * q.lw * v4);
+      gh += gc * (-hw * v1 - q.lw * v2 + hw * v3 + q.lw * v4);
+      gw += gc * (-hh * v1 + hh * v2 - q.lh * v3 + q.lh * v4);
+    }
+  }
+  grad_offset[o] = gh * m;
+  grad_offset[o + P] = gw * m;
+  grad_mask[((size_t)n * K + t) * P + p] = gm;
+}
+
+inline bool dcn_bad(int N, const Conv& g) {
+  return N < 0 || g.C <= 0 || g.H <= 0 || g.W <= 0 || g.Ho <= 0 || g.Wo <= 0 || g.kh <= 0 ||
+         g.kw <= 0 || g.stride <= 0 || g.dil <= 0 || g.pad < 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
+                         int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
+                         int dil, void* stream) {
+  VIDAR_ENTER();
+  Conv g{C, H, W, Ho, Wo, kh, kw, stride, pad, dil};
+  if (dcn_bad(N, g)) return VIDAR_ERR_BAD_ARG;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(dcn_im2col_kernel, dim3((Ho * Wo + 255) / 256, C, N), dim3(256), 0,
+                     (hipStream_t)stream, x, offset, mask, cols, g);
+  return vidar_last_error();
+}
+
+int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* offset,
+                         const float* mask, float* grad_x, float* grad_offset, float* grad_mask,
+                         int N, int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride,
+                         int pad, int dil, void* stream) {
+  VIDAR_ENTER();
+  Conv g{C, H, W, Ho, Wo, kh, kw, stride, pad, dil};
+  if (dcn_bad(N, g)) return VIDAR_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)N * C * H * W, s);
+  if (e != hipSuccess) return (int)e;
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(dcn_col2im_kernel, dim3((Ho * Wo + 255) / 256, C, N), dim3(256), 0, s,
+                     grad_cols, offset, mask, grad_x, g);
+  hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3((Ho * Wo + 255) / 256, kh * kw, N), dim3(256), 0,
+                     s, grad_cols, x, offset, mask, grad_offset, grad_mask, g);
+  return vidar_last_error();
+}
+
+}  // extern "C"

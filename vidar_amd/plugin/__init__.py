@@ -2,7 +2,7 @@
 (same registered type names, constructor kwargs and parameter names).  Importing this package
 registers every module, like `importlib.import_module('projects.mmdet3d_plugin')` does in the
 reference (tools/train.py:113-137)."""
-from . import bricks  # noqa: F401
+from . import bricks, backbones  # noqa: F401
 from .modules import (temporal_self_attention, spatial_cross_attention, encoder, transformer,  # noqa: F401
                       vidar_decoder, vidar_transformer)
 from .modules.ray_operations import latent_rendering  # noqa: F401

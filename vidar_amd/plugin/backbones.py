@@ -1,0 +1,232 @@
+"""Image branch of ViDAR: ResNet (caffe style, frozen BatchNorm, DCNv2 in the last stages) + FPN,
+with the registry names / kwargs / parameter names of mmdet 2.14 `ResNet`, `FPN` and mmcv
+`ModulatedDeformConv2dPack` (third party, not vendored in the reference; config
+vidar_1_8_nusc_1future.py:88-106), so `pretrained/r101_dcn_fcos3d_pretrain.pth`-style checkpoints
+map key for key.  Plain convolutions run on MIOpen through torch; the deformable sampling is the
+gfx950 kernel pair of csrc/dcn.hip and the deformable convolution itself is a hipBLASLt GEMM."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .registry import BACKBONES, NECKS
+from .._lib import lib, check, ptr, stream_of, TIMER
+
+
+class _ModulatedDeformConv(Function):
+    @staticmethod
+    def forward(ctx, x, offset, mask, weight, bias, stride, pad, dil):
+        x, offset, mask = x.float().contiguous(), offset.float().contiguous(), mask.float().contiguous()
+        N, C, H, W = x.shape
+        Cout, _, kh, kw = weight.shape
+        Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        cols = torch.empty((N, C * kh * kw, Ho * Wo), device=x.device)
+        with TIMER.span("dcn_im2col", 4 * (x.numel() + offset.numel() + mask.numel() + cols.numel())):
+            check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(offset), ptr(mask), ptr(cols), N, C, H, W, Ho,
+                                             Wo, kh, kw, stride, pad, dil, stream_of(x)), "dcn_im2col")
+        out = torch.matmul(weight.view(Cout, -1), cols)
+        if bias is not None:
+            out = out + bias.view(1, -1, 1)
+        ctx.save_for_backward(x, offset, mask, weight, cols)
+        ctx.cfg = (stride, pad, dil, Ho, Wo, bias is not None)
+        return out.view(N, Cout, Ho, Wo)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        x, offset, mask, weight, cols = ctx.saved_tensors
+        stride, pad, dil, Ho, Wo, has_bias = ctx.cfg
+        N, C, H, W = x.shape
+        Cout, _, kh, kw = weight.shape
+        go = grad_out.contiguous().view(N, Cout, Ho * Wo)
+        grad_weight = torch.einsum("nop,nkp->ok", go, cols).view_as(weight)
+        grad_cols = torch.matmul(weight.view(Cout, -1).t(), go).contiguous()
+        gx = torch.empty_like(x); goff = torch.empty_like(offset); gm = torch.empty_like(mask)
+        with TIMER.span("dcn_col2im", 4 * (3 * x.numel() + 2 * offset.numel() + 2 * mask.numel() + cols.numel())):
+            check(lib().vidar_dcn_col2im_f32(ptr(grad_cols), ptr(x), ptr(offset), ptr(mask), ptr(gx),
+                                             ptr(goff), ptr(gm), N, C, H, W, Ho, Wo, kh, kw, stride, pad,
+                                             dil, stream_of(x)), "dcn_col2im")
+        return gx, goff, gm, grad_weight, (go.sum((0, 2)) if has_bias else None), None, None, None
+
+
+def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1):
+    return _ModulatedDeformConv.apply(x, offset, mask, weight, bias, int(stride), int(padding), int(dilation))
+
+
+class ModulatedDeformConv2dPack(nn.Module):
+    """mmcv.ops.ModulatedDeformConv2dPack: `conv_offset` (zero-init conv -> 3*K channels), offsets =
+    first 2K channels, mask = sigmoid(last K); parameters `weight`, (`bias`), `conv_offset.*`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, deform_groups=1, bias=True):
+        super().__init__()
+        if groups != 1 or deform_groups != 1:
+            raise NotImplementedError("DCNv2 kernels are built for groups == deform_groups == 1")
+        k = kernel_size
+        self.stride, self.padding, self.dilation, self.k = stride, padding, dilation, k
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        n = in_channels * k * k
+        nn.init.uniform_(self.weight, -1.0 / math.sqrt(n), 1.0 / math.sqrt(n))
+        self.conv_offset = nn.Conv2d(in_channels, 3 * k * k, k, stride, padding, dilation, bias=True)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        out = self.conv_offset(x)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        offset = torch.cat((o1, o2), dim=1)
+        return modulated_deform_conv2d(x, offset, torch.sigmoid(mask), self.weight, self.bias,
+                                       self.stride, self.padding, self.dilation)
+
+
+class FrozenBN(nn.BatchNorm2d):
+    """BN2d with `requires_grad=False` + `norm_eval=True` (config :93-95): always running stats."""
+
+    def __init__(self, c, requires_grad=False):
+        super().__init__(c)
+        for p in self.parameters():
+            p.requires_grad = requires_grad
+
+    def forward(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0,
+                            self.eps)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, style="caffe", dcn=None, bn_grad=False):
+        super().__init__()
+        s1, s2 = (stride, 1) if style == "caffe" else (1, stride)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.bn1 = FrozenBN(planes, bn_grad)
+        if dcn is not None:
+            self.conv2 = ModulatedDeformConv2dPack(planes, planes, 3, stride=s2, padding=1, dilation=1,
+                                                   deform_groups=dcn.get("deform_groups", 1), bias=False)
+        else:
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
+        self.bn2 = FrozenBN(planes, bn_grad)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = FrozenBN(planes * 4, bn_grad)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + identity, inplace=True)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth=101, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1,
+                 norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True, style="pytorch", dcn=None,
+                 stage_with_dcn=(False, False, False, False), strides=(1, 2, 2, 2), in_channels=3,
+                 base_channels=64, init_cfg=None, pretrained=None, **kwargs):
+        super().__init__()
+        if dcn is not None and dcn.get("type") != "DCNv2":
+            raise NotImplementedError(dcn)
+        bn_grad = norm_cfg.get("requires_grad", True)
+        self.out_indices, self.frozen_stages, self.norm_eval = out_indices, frozen_stages, norm_eval
+        self.conv1 = nn.Conv2d(in_channels, base_channels, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBN(base_channels, bn_grad)
+        inplanes = base_channels
+        self.res_layers = []
+        for i, nblocks in enumerate(self.arch[depth][:num_stages]):
+            planes = base_channels * 2 ** i
+            stage_dcn = dcn if stage_with_dcn[i] else None
+            down = None
+            if strides[i] != 1 or inplanes != planes * 4:
+                down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=strides[i], bias=False),
+                                     FrozenBN(planes * 4, bn_grad))
+            blocks = [Bottleneck(inplanes, planes, strides[i], down, style, stage_dcn, bn_grad)]
+            inplanes = planes * 4
+            blocks += [Bottleneck(inplanes, planes, 1, None, style, stage_dcn, bn_grad) for _ in range(1, nblocks)]
+            name = f"layer{i + 1}"
+            self.add_module(name, nn.Sequential(*blocks))
+            self.res_layers.append(name)
+        self._freeze_stages()
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            for p in getattr(self, f"layer{i}").parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x)), inplace=True), 3, stride=2, padding=1)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class _ConvModule(nn.Module):
+    """mmcv ConvModule without norm/activation: parameters under `.conv`."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding)
+        nn.init.xavier_uniform_(self.conv.weight)
+        nn.init.zeros_(self.conv.bias)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1,
+                 add_extra_convs=False, relu_before_extra_convs=False, init_cfg=None, **kwargs):
+        super().__init__()
+        self.start_level = start_level
+        self.backbone_end_level = len(in_channels) if end_level == -1 else end_level
+        self.num_outs = num_outs
+        self.add_extra_convs = "on_input" if add_extra_convs is True else add_extra_convs
+        self.relu_before_extra_convs = relu_before_extra_convs
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(start_level, self.backbone_end_level):
+            self.lateral_convs.append(_ConvModule(in_channels[i], out_channels, 1))
+            self.fpn_convs.append(_ConvModule(out_channels, out_channels, 3, padding=1))
+        extra = num_outs - (self.backbone_end_level - start_level)
+        if self.add_extra_convs and extra >= 1:
+            for i in range(extra):
+                cin = in_channels[self.backbone_end_level - 1] if (i == 0 and self.add_extra_convs == "on_input") else out_channels
+                self.fpn_convs.append(_ConvModule(cin, out_channels, 3, stride=2, padding=1))
+
+    def forward(self, inputs):
+        lat = [l(inputs[i + self.start_level]) for i, l in enumerate(self.lateral_convs)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        outs = [self.fpn_convs[i](lat[i]) for i in range(len(lat))]
+        if self.num_outs > len(outs):
+            if not self.add_extra_convs:
+                for _ in range(self.num_outs - len(outs)):
+                    outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+            else:
+                if self.add_extra_convs == "on_input":
+                    src = inputs[self.backbone_end_level - 1]
+                elif self.add_extra_convs == "on_lateral":
+                    src = lat[-1]
+                else:
+                    src = outs[-1]
+                outs.append(self.fpn_convs[len(lat)](src))
+                for i in range(len(lat) + 1, self.num_outs):
+                    outs.append(self.fpn_convs[i](F.relu(outs[-1]) if self.relu_before_extra_convs else outs[-1]))
+        return tuple(outs)
