@@ -204,6 +204,16 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
                          int N, int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride,
                          int pad, int dil, void* stream);
 
+/* Fused frozen-BatchNorm epilogue of the backbone: y = act(x*scale[c] + shift[c] (+ residual)),
+ * NCHW, scale = gamma/sqrt(var+eps), shift = beta - mean*scale (BN is frozen / eval in every ViDAR
+ * config: vidar_1_8_nusc_1future.py:93-95).  relu: 0/1.  residual / grad_residual may be NULL.
+ * bwd needs y (the forward output) for the ReLU mask; scale/shift receive no gradient (frozen). */
+int vidar_affine_act_fwd_f32(const float* x, const float* scale, const float* shift,
+                             const float* residual, float* y, int N, int C, int HW, int relu,
+                             void* stream);
+int vidar_affine_act_bwd_f32(const float* grad_y, const float* y, const float* scale, float* grad_x,
+                             float* grad_residual, int N, int C, int HW, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

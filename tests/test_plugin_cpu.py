@@ -57,11 +57,16 @@ def test_in_repo_config_state_dict(name):
 def test_released_config_loads_unchanged(name):
     cfg = Config.fromfile(REF_CFG / PATHS[name])
     assert cfg.plugin_dir == "projects/mmdet3d_plugin/" and cfg.model.type == "ViDAR"
-    a = P.build_detector(dict(cfg.model))
-    b = P.build_detector(get_config(name)["model"])
+    a = P.build_detector(dict(cfg.model))              # includes ResNet101-DCNv2 + FPN
+    b = P.build_detector(get_config(name, with_backbone=True)["model"])
     sa = {k: tuple(v.shape) for k, v in a.state_dict().items()}
     sb = {k: tuple(v.shape) for k, v in b.state_dict().items()}
     assert sa == sb
+    assert sa["img_backbone.layer3.0.conv2.conv_offset.weight"] == (27, 256, 3, 3)   # DCNv2 pack
+    assert sa["img_backbone.layer1.0.conv2.weight"] == (64, 64, 3, 3) and "img_neck.fpn_convs.3.conv.weight" in sa
+    frozen = [k for k, p_ in a.named_parameters() if not p_.requires_grad]
+    assert any(k.startswith("img_backbone.layer1.") for k in frozen)               # frozen_stages=1
+    assert not any(k.startswith("img_backbone.layer2.0.conv1") for k in frozen)
 
 
 def test_config_overrides_and_base(tmp_path):

@@ -30,6 +30,7 @@ PER_FILE: dict[str, list[str]] = {
     # pure fp32 interpolation arithmetic, tolerance-checked: let the compiler fuse multiply-adds
     "msda.hip": ["-ffp-contract=fast"],
     "dcn.hip": ["-ffp-contract=fast"],
+    "affine_act.hip": ["-ffp-contract=fast"],
 }
 
 

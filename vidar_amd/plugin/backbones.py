@@ -30,7 +30,7 @@ class _ModulatedDeformConv(Function):
         with TIMER.span("dcn_im2col", 4 * (x.numel() + offset.numel() + mask.numel() + cols.numel())):
             check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(offset), ptr(mask), ptr(cols), N, C, H, W, Ho,
                                              Wo, kh, kw, stride, pad, dil, stream_of(x)), "dcn_im2col")
-        out = torch.matmul(weight.view(Cout, -1), cols)
+        out = torch.matmul(weight.reshape(Cout, -1), cols)
         if bias is not None:
             out = out + bias.view(1, -1, 1)
         ctx.save_for_backward(x, offset, mask, weight, cols)
@@ -45,8 +45,8 @@ class _ModulatedDeformConv(Function):
         N, C, H, W = x.shape
         Cout, _, kh, kw = weight.shape
         go = grad_out.contiguous().view(N, Cout, Ho * Wo)
-        grad_weight = torch.einsum("nop,nkp->ok", go, cols).view_as(weight)
-        grad_cols = torch.matmul(weight.view(Cout, -1).t(), go).contiguous()
+        grad_weight = torch.einsum("nop,nkp->ok", go, cols).reshape(weight.shape)
+        grad_cols = torch.matmul(weight.reshape(Cout, -1).t(), go).contiguous()
         gx = torch.empty_like(x); goff = torch.empty_like(offset); gm = torch.empty_like(mask)
         with TIMER.span("dcn_col2im", 4 * (3 * x.numel() + 2 * offset.numel() + 2 * mask.numel() + cols.numel())):
             check(lib().vidar_dcn_col2im_f32(ptr(grad_cols), ptr(x), ptr(offset), ptr(mask), ptr(gx),
@@ -86,17 +86,68 @@ class ModulatedDeformConv2dPack(nn.Module):
                                        self.stride, self.padding, self.dilation)
 
 
+class _AffineAct(Function):
+    """y = act(x*scale[c] + shift[c] (+ residual)) in one pass (csrc/affine_act.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        x = x.float().contiguous()
+        N, C, H, W = x.shape
+        res = residual.float().contiguous() if residual is not None else None
+        y = torch.empty_like(x)
+        with TIMER.span("affine_act_fwd", 4 * x.numel() * (3 if res is not None else 2)):
+            check(lib().vidar_affine_act_fwd_f32(ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(y), N, C,
+                                                 H * W, int(relu), stream_of(x)), "affine_act_fwd")
+        ctx.save_for_backward(y, scale)
+        ctx.cfg = (relu, residual is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        y, scale = ctx.saved_tensors
+        relu, has_res = ctx.cfg
+        gy = gy.float().contiguous()
+        N, C, H, W = y.shape
+        gx = torch.empty_like(y)
+        gres = torch.empty_like(y) if has_res else None
+        with TIMER.span("affine_act_bwd", 4 * y.numel() * (4 if has_res else 3)):
+            check(lib().vidar_affine_act_bwd_f32(ptr(gy), ptr(y), ptr(scale), ptr(gx), ptr(gres), N, C,
+                                                 H * W, int(relu), stream_of(y)), "affine_act_bwd")
+        return gx, None, None, gres, None
+
+
 class FrozenBN(nn.BatchNorm2d):
-    """BN2d with `requires_grad=False` + `norm_eval=True` (config :93-95): always running stats."""
+    """BN2d with `requires_grad=False` + `norm_eval=True` (config :93-95): always running stats.
+    `forward(x, residual=None, relu=False)` fuses the affine with the residual add and the ReLU that
+    follow it in a bottleneck.  A trainable affine (requires_grad=True configs) falls back to
+    F.batch_norm + separate ops so that gamma/beta receive gradients."""
 
     def __init__(self, c, requires_grad=False):
         super().__init__(c)
         for p in self.parameters():
             p.requires_grad = requires_grad
+        self._cache = None
 
-    def forward(self, x):
-        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0,
-                            self.eps)
+    def _scale_shift(self):
+        key = (self.weight._version, self.bias._version, self.running_mean._version,
+               self.running_var._version, self.weight.device)
+        if self._cache is None or self._cache[0] != key:
+            with torch.no_grad():
+                scale = (self.weight / torch.sqrt(self.running_var + self.eps)).float().contiguous()
+                shift = (self.bias - self.running_mean * scale).float().contiguous()
+            self._cache = (key, scale, shift)
+        return self._cache[1], self._cache[2]
+
+    def forward(self, x, residual=None, relu=False):
+        if self.weight.requires_grad or not x.is_cuda:
+            y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0,
+                             self.eps)
+            if residual is not None:
+                y = y + residual
+            return F.relu(y, inplace=True) if relu else y
+        scale, shift = self._scale_shift()
+        return _AffineAct.apply(x, scale, shift, residual, relu)
 
 
 class Bottleneck(nn.Module):
@@ -119,10 +170,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
-        out = F.relu(self.bn1(self.conv1(x)), inplace=True)
-        out = F.relu(self.bn2(self.conv2(out)), inplace=True)
-        out = self.bn3(self.conv3(out))
-        return F.relu(out + identity, inplace=True)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), residual=identity, relu=True)
 
 
 @BACKBONES.register_module()
@@ -167,7 +217,7 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x)), inplace=True), 3, stride=2, padding=1)
+        x = F.max_pool2d(self.bn1(self.conv1(x), relu=True), 3, stride=2, padding=1)
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)
