@@ -148,14 +148,17 @@ def main():
 
     for _ in range(args.warmup):
         T.train_step(ddp, opt, batch, cfg["grad_clip"])
+    from vidar_amd._lib import lib as _hip
     TIMER.reset()
     TIMER.enabled = True
     sync()
+    _hip().vidar_marker(1, None)                 # delimits the timed region in a rocprofv3 trace
     t0 = time.perf_counter()
     for _ in range(args.steps):
         T.train_step(ddp, opt, batch, cfg["grad_clip"])
     sync()
     elapsed = time.perf_counter() - t0
+    _hip().vidar_marker(2, None)
     TIMER.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

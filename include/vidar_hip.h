@@ -27,6 +27,8 @@ extern "C" {
 
 /* ABI revision of this header; bumped whenever a signature changes. */
 int vidar_abi_version(void);
+/* profiling aid: launches the empty kernel `vidar_marker_kernel` on `stream` (see tools/trace_stats.py) */
+int vidar_marker(int id, void* stream);
 
 /* ---------------------------------------------------------------------------
  * third_lib/dvr  (pybind surface: third_lib/dvr/dvr.cpp:36-69)
