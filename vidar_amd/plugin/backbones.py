@@ -30,7 +30,8 @@ class _ModulatedDeformConv(Function):
         with TIMER.span("dcn_im2col", 4 * (x.numel() + offset.numel() + mask.numel() + cols.numel())):
             check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(offset), ptr(mask), ptr(cols), N, C, H, W, Ho,
                                              Wo, kh, kw, stride, pad, dil, stream_of(x)), "dcn_im2col")
-        out = torch.matmul(weight.reshape(Cout, -1), cols)
+        # bmm with a broadcast (stride-0) weight: torch.matmul(2-D, 3-D) would transpose-copy `cols`
+        out = torch.bmm(weight.reshape(1, Cout, -1).expand(N, -1, -1), cols)
         if bias is not None:
             out = out + bias.view(1, -1, 1)
         ctx.save_for_backward(x, offset, mask, weight, cols)
@@ -45,8 +46,8 @@ class _ModulatedDeformConv(Function):
         N, C, H, W = x.shape
         Cout, _, kh, kw = weight.shape
         go = grad_out.contiguous().view(N, Cout, Ho * Wo)
-        grad_weight = torch.einsum("nop,nkp->ok", go, cols).reshape(weight.shape)
-        grad_cols = torch.matmul(weight.reshape(Cout, -1).t(), go).contiguous()
+        grad_weight = torch.bmm(go, cols.transpose(1, 2)).sum(0).reshape(weight.shape)
+        grad_cols = torch.bmm(weight.reshape(1, Cout, -1).transpose(1, 2).expand(N, -1, -1), go)
         gx = torch.empty_like(x); goff = torch.empty_like(offset); gm = torch.empty_like(mask)
         with TIMER.span("dcn_col2im", 4 * (3 * x.numel() + 2 * offset.numel() + 2 * mask.numel() + cols.numel())):
             check(lib().vidar_dcn_col2im_f32(ptr(grad_cols), ptr(x), ptr(offset), ptr(mask), ptr(gx),
