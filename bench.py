@@ -28,6 +28,13 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB -> bytes; FETCH not
+# doubled: the x2 rule of the microarch guide is calibrated for wide coalesced streams only).
+# Source: profiles/r01_pmc_{FETCH,WRITE}_SIZE_kbench_msda_lr.csv (tools/pmc_traffic.sh, SCA shape
+# B=6, Nq=10^4, L=4, P=8 / TSA shape B=2, Nq=4*10^4).  Atomic read-modify-writes show up as writes.
+PMC_TRAFFIC = {"msda_bwd[L=4,P=8]": (1392835.0 + 5508074.1) * 1024,
+               # TSA row = 3*mean - min(Pred) - max(SCA) of the 39 equally split dispatches
+               "msda_bwd[L=1,P=4]": (457348.7 + 920731.2) * 1024}
 
 
 def parse():
@@ -188,7 +195,8 @@ def main():
                        "global_batch": world, "rays_per_frame": args.rays_per_frame,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": PMC_TRAFFIC.get(dom_name),
                          "avg_ms": dom["avg_ms"], "launches_per_step": dom["calls"] / args.steps,
                          "hip_ops_ms_per_step": hip_ms},
         }
