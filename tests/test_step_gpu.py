@@ -26,6 +26,13 @@ def test_hip_step_matches_cpu_oracle_step(name):
     for m in model.modules():
         if hasattr(m, "random_drop_prev_rate"):
             m.random_drop_prev_rate = 0.0
+    # BEV self-attention starts with every sampling point exactly ON a pixel centre (integer ring
+    # offsets around cell centres): there the bilinear kernel has a kink and d/d(location) is
+    # one-sided, so CPU and GPU may legitimately pick different sides.  Move off the kinks.
+    g_ = torch.Generator().manual_seed(11)
+    for n_, p_ in model.named_parameters():
+        if n_.endswith("sampling_offsets.bias"):
+            p_.data += torch.randn(p_.shape, generator=g_) * 0.3
     noise = -torch.empty(20000, 512).exponential_(generator=torch.Generator().manual_seed(3)).log()
     model.future_pred_head.gumbel_noise_fn = lambda R, K: noise[:R].to(next(model.parameters()).device)
     model.train(); model.apply(lambda m: setattr(m, "p", 0.0) if isinstance(m, torch.nn.Dropout) else None)
