@@ -16,7 +16,8 @@
 // Mapping: one wave per BEV cell; lane = (k mod 16, quarter of the 16 bins as a float4); the ray is
 // walked 16 waypoints per iteration and reduced over the 16 k-lanes with xor shuffles.  Cells are
 // assigned to workgroups in row-major order, 4 cells per 256-thread workgroup.
-// Backward kernels recompute the forward samples and scatter with fp32 hardware atomics.
+// Backward kernels recompute the forward samples and scatter with fp32 hardware atomics, with the
+// lane map (waypoint k mod 4, height bin) so that one atomic instruction covers a corner's 64 bytes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -92,21 +93,6 @@ __device__ __forceinline__ float4 tap_load(const float* __restrict__ map, const 
     }
   }
   return acc;
-}
-
-__device__ __forceinline__ void tap_scatter(float* __restrict__ map, const Tap& t, int zq,
-                                            const float4& g) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (t.o[c] >= 0) {
-      float* p = map + (size_t)t.o[c] * kZ + zq * 4;
-      const float w = t.w[c];
-      if (g.x != 0.f) unsafeAtomicAdd(p + 0, w * g.x);
-      if (g.y != 0.f) unsafeAtomicAdd(p + 1, w * g.y);
-      if (g.z != 0.f) unsafeAtomicAdd(p + 2, w * g.z);
-      if (g.w != 0.f) unsafeAtomicAdd(p + 3, w * g.w);
-    }
-  }
 }
 
 __device__ __forceinline__ float act_f(float x, int act) {
