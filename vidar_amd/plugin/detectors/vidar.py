@@ -106,7 +106,10 @@ class ViDAR(nn.Module):
         if was_training:
             self.eval()
         with torch.no_grad():
-            feats = self._queue_feats(img, img_feats, img_metas_list, 0, split, grad=False) if split > 0 else None
+            # image features of ALL history frames are frozen (eval, no grad) -- also those of the
+            # back-propagated frames (bevformer.py:196-205) -- so one backbone pass serves both loops
+            feats = self._queue_feats(img, img_feats, img_metas_list, 0, num_frames, grad=False) \
+                if num_frames > 0 else None
             for i in range(split):
                 metas = [m[i] for m in img_metas_list]
                 if not metas[0]["prev_bev_exists"]:
@@ -114,15 +117,13 @@ class ViDAR(nn.Module):
                 prev_bev = self.pts_bbox_head([f[:, i] for f in feats], metas, prev_bev, only_bev=True)
                 if i < drop_prev_index:
                     prev_bev = None
-            if back > 0:       # image features of the back-propagated frames are still frozen/eval
-                feats_b = self._queue_feats(img, img_feats, img_metas_list, split, num_frames, grad=False)
         if was_training:
             self.train()
-        for j, i in enumerate(range(split, num_frames)):
+        for i in range(split, num_frames):
             metas = [m[i] for m in img_metas_list]
             if not metas[0]["prev_bev_exists"]:
                 prev_bev = None
-            prev_bev = self.pts_bbox_head([f[:, j] for f in feats_b], metas, prev_bev, only_bev=True)
+            prev_bev = self.pts_bbox_head([f[:, i] for f in feats], metas, prev_bev, only_bev=True)
         return prev_bev
 
     # ---- future alignment (vidar.py:175-237) -------------------------------------------------------
