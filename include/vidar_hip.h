@@ -123,6 +123,8 @@ int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
  * bwd: grad_value is zeroed by the call then accumulated with fp32 atomics; grad_sampling_loc and
  * grad_attn_weight are fully written (the reference expects pre-zeroed buffers, function.py:146-148).
  * ------------------------------------------------------------------------- */
+/* tuning/A-B switch: 1 (default) = XCD-banded workgroup order, 0 = plain blockIdx order */
+int vidar_msda_set_xcd_remap(int enabled);
 int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq,

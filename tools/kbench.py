@@ -74,6 +74,16 @@ def bench_knn(which):
                fp32_TFLOPs=round(P1 * P2 * 8 / ms / 1e9, 2))
 
 
+def bench_msda_ab(which):
+    """XCD-banded vs plain workgroup order (A/B)."""
+    from vidar_amd._lib import lib
+    for flag in (1, 0, 1, 0):
+        lib().vidar_msda_set_xcd_remap(flag)
+        print(json.dumps({"xcd_remap": flag}))
+        bench_msda(which)
+    lib().vidar_msda_set_xcd_remap(1)
+
+
 def bench_msda(which):
     from oracle import msda as M   # operand generator only (bench tool, not product)
     from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_forward, _msda_backward
