@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ grad_out, float* __restrict__ grad_value,
     float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv, int H, int Nq, int L, int P,
-    int64_t n_items, int nblocks, int first_pull_level) {
+    int64_t n_items, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
   float* s_loc = smem;                         // [kBItems][LP*2]  in: loc, out: grad_loc
@@ -181,13 +181,11 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
           gw = c.w00 * d00 + c.w01 * d01 + c.w10 * d10 + c.w11 * d11;
           gx = w * Wl * (-hh * d00 + hh * d01 - c.lh * d10 + c.lh * d11);
           gy = w * Hl * (-hw * d00 - c.lw * d01 + hw * d10 + c.lw * d11);
-          if (l < first_pull_level) {     // coarser levels: msda_bwd_pull_kernel, no atomics
-            const float wg = w * go;
-            if (c.o00 >= 0) unsafeAtomicAdd(gvb + c.o00, c.w00 * wg);
-            if (c.o01 >= 0) unsafeAtomicAdd(gvb + c.o01, c.w01 * wg);
-            if (c.o10 >= 0) unsafeAtomicAdd(gvb + c.o10, c.w10 * wg);
-            if (c.o11 >= 0) unsafeAtomicAdd(gvb + c.o11, c.w11 * wg);
-          }
+          const float wg = w * go;
+          if (c.o00 >= 0) unsafeAtomicAdd(gvb + c.o00, c.w00 * wg);
+          if (c.o01 >= 0) unsafeAtomicAdd(gvb + c.o01, c.w01 * wg);
+          if (c.o10 >= 0) unsafeAtomicAdd(gvb + c.o10, c.w10 * wg);
+          if (c.o11 >= 0) unsafeAtomicAdd(gvb + c.o11, c.w11 * wg);
         }
         gx = half_wave_sum(gx); gy = half_wave_sum(gy); gw = half_wave_sum(gw);
         // all 32 lanes consumed (x, y, w) of this point before the shuffles finished
@@ -202,72 +200,6 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
   __syncthreads();
   for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) grad_loc[item0 * LP * 2 + i] = s_loc[i];
   for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) grad_w[item0 * LP + i] = s_w[i];
-}
-
-// ---------------------------------------------------------------------------------------------
-// grad_value of the coarse pyramid levels without atomics ("pull by region").  On the coarse levels
-// of the camera pyramids hundreds of samples land on every (pixel, head) line, so pushing them
-// through memory-side atomics (one request each) is the expensive way round.  Here a workgroup OWNS
-// a run of kRegPx consecutive pixels of one level for one (batch, head): it scans the sampling
-// points of every query of that (batch, head, level) -- 12 bytes per point, L2 resident --
-// accumulates the hits in LDS (ds_add_f32, 32 lanes = 32 channels = 32 banks) and finally writes
-// its region with plain coalesced stores.
-// ---------------------------------------------------------------------------------------------
-constexpr int kRegPx = 352;            // 352 px x 128 B = 44 KiB of LDS -> 3 workgroups per CU
-
-__global__ __launch_bounds__(kThreads) void msda_bwd_pull_kernel(
-    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-    const float* __restrict__ loc, const float* __restrict__ attw,
-    const float* __restrict__ grad_out, float* __restrict__ grad_value, int Nv, int H, int Nq, int L,
-    int P, int first_pull_level) {
-  __shared__ float acc[kRegPx * kCh];
-  // which (level, region) is this workgroup?
-  int rid = blockIdx.x, lvl = -1, Hl = 0, Wl = 0;
-  for (int l = first_pull_level; l < L; ++l) {
-    const int h_ = (int)shapes[2 * l], w_ = (int)shapes[2 * l + 1];
-    const int nreg = (h_ * w_ + kRegPx - 1) / kRegPx;
-    if (rid < nreg) { lvl = l; Hl = h_; Wl = w_; break; }
-    rid -= nreg;
-  }
-  if (lvl < 0) return;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int p0 = rid * kRegPx, p1 = min(p0 + kRegPx, Hl * Wl);
-  for (int i = threadIdx.x; i < kRegPx * kCh; i += kThreads) acc[i] = 0.f;
-  __syncthreads();
-  const int grp = threadIdx.x / kBLanes, ch = threadIdx.x % kBLanes;
-  const int LP = L * P;
-  for (int q = grp; q < Nq; q += kBItems) {
-    const int64_t item = ((int64_t)b * Nq + q) * H + h;
-    // lanes 0..2P-1 fetch the (x, y) pairs of this level, lanes 2P..3P-1 the weights
-    float mine = 0.f;
-    if (ch < 2 * P) mine = loc[item * LP * 2 + (int64_t)lvl * P * 2 + ch];
-    else if (ch < 3 * P) mine = attw[item * LP + (int64_t)lvl * P + (ch - 2 * P)];
-    float go = 0.f;
-    bool have_go = false;
-    for (int p = 0; p < P; ++p) {
-      const float x = __shfl(mine, 2 * p, kBLanes) * Wl - 0.5f;
-      const float y = __shfl(mine, 2 * p + 1, kBLanes) * Hl - 0.5f;
-      const float w = __shfl(mine, 2 * P + p, kBLanes);
-      if (!(y > -1.f && x > -1.f && y < Hl && x < Wl)) continue;
-      const int h0 = (int)floorf(y), w0 = (int)floorf(x);
-      const int q00 = h0 * Wl + w0;                 // flattened index of the top-left corner
-      if (q00 + Wl + 1 < p0 || q00 >= p1) continue; // footprint cannot touch the region
-      if (!have_go) { go = grad_out[item * kCh + ch]; have_go = true; }
-      const float lh = y - h0, lw = x - w0, hh = 1.f - lh, hw = 1.f - lw;
-      const bool t_ = h0 >= 0, b_ = h0 + 1 <= Hl - 1, l_ = w0 >= 0, r_ = w0 + 1 <= Wl - 1;
-      const float wg = w * go;
-      const int c00 = q00, c01 = q00 + 1, c10 = q00 + Wl, c11 = q00 + Wl + 1;
-      if (t_ && l_ && c00 >= p0 && c00 < p1) atomicAdd(&acc[(c00 - p0) * kCh + ch], hh * hw * wg);
-      if (t_ && r_ && c01 >= p0 && c01 < p1) atomicAdd(&acc[(c01 - p0) * kCh + ch], hh * lw * wg);
-      if (b_ && l_ && c10 >= p0 && c10 < p1) atomicAdd(&acc[(c10 - p0) * kCh + ch], lh * hw * wg);
-      if (b_ && r_ && c11 >= p0 && c11 < p1) atomicAdd(&acc[(c11 - p0) * kCh + ch], lh * lw * wg);
-    }
-  }
-  __syncthreads();
-  float* out = grad_value + (((int64_t)b * Nv + lsi[lvl] + p0) * H + h) * kCh;
-  const int row = H * kCh;
-  for (int i = threadIdx.x; i < (p1 - p0) * kCh; i += kThreads)
-    out[(int64_t)(i / kCh) * row + (i % kCh)] = acc[i];
 }
 
 inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
@@ -318,19 +250,9 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
   const int grid = ((nblocks + 7) / 8) * 8;
   const size_t lds = sizeof(float) * kBItems * L * P * 3;
-  // multi-level (camera pyramid) maps: level 0 by atomics, levels >= 1 pulled by region
-  const int first_pull_level = (L > 1 && 3 * P <= kBLanes) ? 1 : L;
   hipLaunchKernelGGL(msda_bwd_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                      level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
-                     grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks,
-                     first_pull_level);
-  if (first_pull_level < L) {
-    // region count is bounded by the pixels of all levels (shapes live on the device)
-    const int max_regions = (Nv + kRegPx - 1) / kRegPx + L;
-    hipLaunchKernelGGL(msda_bwd_pull_kernel, dim3(max_regions, H, B), dim3(kThreads), 0, s,
-                       spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
-                       grad_value, Nv, H, Nq, L, P, first_pull_level);
-  }
+                     grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks);
   return vidar_last_error();
 }
 
