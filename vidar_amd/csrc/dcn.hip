@@ -72,85 +72,33 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
   }
 }
 
-// grad wrt input.  A workgroup owns a 16x16 tile of output pixels and walks kCPB channels; for each
-// channel the 9 taps x 4 corners of its 256 pixels are first summed in an LDS window that covers the
-// tile's receptive field plus a margin of kMargin pixels for the learned offsets (plain index
-// arithmetic, ds_add_f32), and the window then leaves with ONE global atomic per touched cell --
-// ~16x fewer memory-side atomic requests than scattering every contribution (contributions that
-// fall outside the window still go straight to global atomics).  Offsets and mask of a pixel are
-// read once and reused for all kCPB channels.
-constexpr int kTile = 16;
-constexpr int kCPB = 16;
-constexpr int kMargin = 4;
-constexpr int kMaxTaps = 9;
-
-// grid: (tiles_x * tiles_y, ceil(C / kCPB), N); dynamic LDS: win_h * win_w floats
-__global__ __launch_bounds__(kTile * kTile) void dcn_col2im_kernel(
-    const float* __restrict__ grad_cols, const float* __restrict__ offset,
-    const float* __restrict__ mask, float* __restrict__ grad_x, Conv g) {
-  extern __shared__ __attribute__((aligned(16))) float win[];
+// grad wrt input: scatter grad_cols * mask * corner weights (atomics); grid as im2col
+__global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ grad_cols,
+                                                         const float* __restrict__ offset,
+                                                         const float* __restrict__ mask,
+                                                         float* __restrict__ grad_x, Conv g) {
   const int P = g.Ho * g.Wo, K = g.kh * g.kw;
-  const int tiles_x = (g.Wo + kTile - 1) / kTile;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
-  const int n = blockIdx.z, c0 = blockIdx.y * kCPB;
-  const int py = ty * kTile + threadIdx.x / kTile, px = tx * kTile + threadIdx.x % kTile;
-  const bool live = py < g.Ho && px < g.Wo;
-  const int p = live ? py * g.Wo + px : 0;
-  // window origin / extent in input coordinates
-  const int wy0 = ty * kTile * g.stride - g.pad - kMargin, wx0 = tx * kTile * g.stride - g.pad - kMargin;
-  const int wh = (kTile - 1) * g.stride + (g.kh - 1) * g.dil + 2 + 2 * kMargin;
-  const int ww = (kTile - 1) * g.stride + (g.kw - 1) * g.dil + 2 + 2 * kMargin;
-  // this pixel's sampling footprints (shared by every channel)
-  float sh[kMaxTaps], sw[kMaxTaps], sm[kMaxTaps];
-#pragma unroll
-  for (int t = 0; t < kMaxTaps; ++t) {
-    sh[t] = sw[t] = sm[t] = 0.f;
-    if (live && t < K) {
-      const int i = t / g.kw, j = t % g.kw;
-      sh[t] = py * g.stride - g.pad + i * g.dil + offset[((size_t)n * 2 * K + 2 * t) * P + p];
-      sw[t] = px * g.stride - g.pad + j * g.dil + offset[((size_t)n * 2 * K + 2 * t + 1) * P + p];
-      sm[t] = mask[((size_t)n * K + t) * P + p];
-    }
-  }
-  for (int c = c0; c < min(c0 + kCPB, g.C); ++c) {
-    for (int i = threadIdx.x; i < wh * ww; i += kTile * kTile) win[i] = 0.f;
-    __syncthreads();
-    float* gim = grad_x + ((size_t)n * g.C + c) * g.H * g.W;
-    if (live) {
-      const float* gc = grad_cols + ((size_t)n * g.C + c) * K * P + p;
-#pragma unroll
-      for (int t = 0; t < kMaxTaps; ++t) {
-        if (t >= K) break;
-        const Bil q = bil(sh[t], sw[t], g.H, g.W);
-        if (!q.in) continue;
-        const float gv = gc[(size_t)t * P] * sm[t];
-        if (gv == 0.f) continue;
-        const float hh = 1.f - q.lh, hw = 1.f - q.lw;
-        const int ly = q.h0 - wy0, lx = q.w0 - wx0;
-        const bool inwin = ly >= 0 && ly + 1 < wh && lx >= 0 && lx + 1 < ww;
-        if (inwin) {
-          float* w0 = win + ly * ww + lx;
-          if (q.t && q.l) atomicAdd(w0, hh * hw * gv);
-          if (q.t && q.r) atomicAdd(w0 + 1, hh * q.lw * gv);
-          if (q.b && q.l) atomicAdd(w0 + ww, q.lh * hw * gv);
-          if (q.b && q.r) atomicAdd(w0 + ww + 1, q.lh * q.lw * gv);
-        } else {
-          if (q.t && q.l) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0, hh * hw * gv);
-          if (q.t && q.r) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0 + 1, hh * q.lw * gv);
-          if (q.b && q.l) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0, q.lh * hw * gv);
-          if (q.b && q.r) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0 + 1, q.lh * q.lw * gv);
-        }
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < wh * ww; i += kTile * kTile) {
-      const float v = win[i];
-      if (v != 0.f) {
-        const int y = wy0 + i / ww, x = wx0 + i % ww;   // in-window cells only ever hold in-image taps
-        unsafeAtomicAdd(gim + y * g.W + x, v);
-      }
-    }
-    __syncthreads();
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int py = p / g.Wo, px = p % g.Wo;
+  float* gim = grad_x + ((size_t)n * g.C + c) * g.H * g.W;
+  const float* off = offset + (size_t)n * 2 * K * P + p;
+  const float* mk = mask + (size_t)n * K * P + p;
+  const float* gc = grad_cols + ((size_t)n * g.C + c) * K * P + p;
+  for (int t = 0; t < K; ++t) {
+    const int i = t / g.kw, j = t % g.kw;
+    const float h = py * g.stride - g.pad + i * g.dil + off[(size_t)(2 * t) * P];
+    const float w = px * g.stride - g.pad + j * g.dil + off[(size_t)(2 * t + 1) * P];
+    const Bil q = bil(h, w, g.H, g.W);
+    if (!q.in) continue;
+    const float gv = gc[(size_t)t * P] * mk[(size_t)t * P];
+    if (gv == 0.f) continue;
+    const float hh = 1.f - q.lh, hw = 1.f - q.lw;
+    if (q.t && q.l) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0, hh * hw * gv);
+    if (q.t && q.r) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0 + 1, hh * q.lw * gv);
+    if (q.b && q.l) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0, q.lh * hw * gv);
+    if (q.b && q.r) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0 + 1, q.lh * q.lw * gv);
   }
 }
 
@@ -223,14 +171,8 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
   hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)N * C * H * W, s);
   if (e != hipSuccess) return (int)e;
   if (N == 0) return 0;
-  if (kh * kw > kMaxTaps) return VIDAR_ERR_BAD_ARG;
-  {
-    const int tiles = ((Ho + kTile - 1) / kTile) * ((Wo + kTile - 1) / kTile);
-    const int wh = (kTile - 1) * stride + (kh - 1) * dil + 2 + 2 * kMargin;
-    const int ww = (kTile - 1) * stride + (kw - 1) * dil + 2 + 2 * kMargin;
-    hipLaunchKernelGGL(dcn_col2im_kernel, dim3(tiles, (C + kCPB - 1) / kCPB, N), dim3(kTile * kTile),
-                       sizeof(float) * wh * ww, s, grad_cols, offset, mask, grad_x, g);
-  }
+  hipLaunchKernelGGL(dcn_col2im_kernel, dim3((Ho * Wo + 255) / 256, C, N), dim3(256), 0, s,
+                     grad_cols, offset, mask, grad_x, g);
   hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3((Ho * Wo + 255) / 256, kh * kw, N), dim3(256), 0,
                      s, grad_cols, x, offset, mask, grad_offset, grad_mask, g);
   return vidar_last_error();
