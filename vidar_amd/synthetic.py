@@ -61,7 +61,7 @@ def ray_set(seed=0, N=1, T=1, rays_per_frame=30000, grid=(16, 200, 200), pad=0, 
 # transforms, LiDAR-like GT clouds with the frame index in the last column, FPN feature pyramids.
 # --------------------------------------------------------------------------------------------------
 FPN_SHAPES_NUSC = [(116, 200), (58, 100), (29, 50), (15, 25)]      # 928x1600 input, strides 8..64
-CAM_YAWS_DEG = (0.0, 55.0, -55.0, 110.0, -110.0, 180.0)
+CAM_YAWS_DEG = (0.0, 55.0, -55.0, 110.0, -110.0, 180.0, 27.0, -27.0)   # nuScenes-like 6 (+2 for OpenScene's 8)
 
 
 def _pose(x, y, yaw):
@@ -106,7 +106,8 @@ def make_sample(seed=0, queue_length=4, future_frames=2, rays_per_frame=30000, i
     inv = np.linalg.inv
     cur2ref = [(inv(poses[ref]) @ poses[k]).T for k in range(n_all)]     # row-vector convention
     ref2cur = [(inv(poses[k]) @ poses[ref]).T for k in range(n_all)]
-    lidar2img = camera_matrices(img_hw)[:num_cams]
+    lidar2img = camera_matrices(img_hw, centre=(img_hw[1] / 2.0, img_hw[0] / 2.0 - 14.0))[:num_cams]
+    assert lidar2img.shape[0] == num_cams, "extend CAM_YAWS_DEG for more cameras"
     metas = []
     for k in range(T):
         can_bus = np.zeros(18)
