@@ -77,28 +77,6 @@ class BEVFormerEncoder(TransformerLayerSequence):
         mask = torch.nan_to_num(mask)
         return xy.permute(2, 1, 3, 0, 4), mask.permute(2, 1, 3, 0, 4).squeeze(-1)
 
-    def visible_upper_bound(self, bev_h, bev_w, img_metas, margin=256):
-        """Host-side (numpy, fp32) replay of point_sampling's visibility test for batch item 0: an
-        upper bound (+margin for fp rounding at the image border) of the number of BEV queries any
-        camera sees.  It sizes the compacted SCA batch without a device->host sync; the device mask
-        stays authoritative for which slots are live."""
-        pc = self.pc_range
-        D = self.num_points_in_pillar
-        Z = pc[5] - pc[2]
-        xs = (np.arange(bev_w, dtype=np.float32) + 0.5) / bev_w * (pc[3] - pc[0]) + pc[0]
-        ys = (np.arange(bev_h, dtype=np.float32) + 0.5) / bev_h * (pc[4] - pc[1]) + pc[1]
-        zs = np.linspace(0.5, Z - 0.5, D, dtype=np.float32) / Z * (pc[5] - pc[2]) + pc[2]
-        gx, gy, gz = np.meshgrid(xs, ys, zs, indexing="xy")            # [H, W, D]
-        pts = np.stack([gx, gy, gz, np.ones_like(gx)], -1).reshape(-1, D, 4).astype(np.float32)
-        l2i = np.asarray(img_metas[0]["lidar2img"], dtype=np.float32)    # [cams, 4, 4]
-        cam = np.einsum("nij,qdj->nqdi", l2i, pts)
-        z = cam[..., 2]
-        h, w = img_metas[0]["img_shape"][0][0], img_metas[0]["img_shape"][0][1]
-        zc = np.maximum(z, 1e-5)
-        u, v = cam[..., 0] / zc / w, cam[..., 1] / zc / h
-        vis = ((z > 1e-5) & (u > 0) & (u < 1) & (v > 0) & (v < 1)).any(-1)    # [cams, Q]
-        return int(min(bev_h * bev_w, vis.sum(1).max() + margin))
-
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
                 shift=0., **kwargs):
@@ -111,9 +89,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
         ref_2d = self.get_reference_points(bev_h, bev_w, dim="2d", bs=bs, device=bev_query.device,
                                            dtype=bev_query.dtype)
         reference_points_cam, bev_mask = self.point_sampling(ref_3d, self.pc_range, kwargs["img_metas"])
-        # compaction table once per pass (the reference: one nonzero() sync per camera per layer)
-        sca_index = visible_query_index(
-            bev_mask, self.visible_upper_bound(bev_h, bev_w, kwargs["img_metas"]))
+        sca_index = visible_query_index(bev_mask)        # once per pass instead of once per layer
         shift_ref_2d = ref_2d.clone() + shift[:, None, None, :]
         bev_query = bev_query.permute(1, 0, 2)
         bev_pos = bev_pos.permute(1, 0, 2)

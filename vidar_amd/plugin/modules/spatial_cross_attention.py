@@ -16,15 +16,13 @@ from ._attn_common import init_deformable_offsets
 from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32
 
 
-def visible_query_index(bev_mask, max_len_hint=None):
+def visible_query_index(bev_mask):
     """bev_mask [cams, bs, Q, D] bool -> (idx [cams, max_len] long, valid [cams, max_len] bool,
     count [bs, Q] float).  Like the reference the visible set is taken from batch item 0 (:137-139).
-    `max_len_hint`: an upper bound of the per-camera visible count known on the host (see
-    BEVFormerEncoder.visible_upper_bound) -- with it nothing is read back from the device; without it
-    one device->host read (max_len) happens.  Padded slots are masked by `valid` either way."""
+    One device->host read (max_len)."""
     vis = bev_mask[:, 0].sum(-1) > 0                       # [cams, Q]
     lens = vis.sum(1)
-    max_len = int(max_len_hint) if max_len_hint is not None else int(lens.max())
+    max_len = int(lens.max())                              # the only sync
     order = torch.argsort((~vis).to(torch.int8), dim=1, stable=True)[:, :max_len]
     valid = torch.arange(max_len, device=vis.device)[None] < lens[:, None]
     count = (bev_mask.sum(-1) > 0).permute(1, 2, 0).sum(-1).clamp(min=1.0)
