@@ -92,3 +92,65 @@ def train_step(model, optimizer, batch, max_norm=35.0):
     torch.nn.utils.clip_grad_norm_(params, max_norm)
     optimizer.step()
     return total.detach(), {k: v.detach() for k, v in losses.items()}
+
+
+class CosineWithWarmup:
+    """lr_config of the released configs (vidar_1_8_nusc_3future.py:387-395): CosineAnnealing with a
+    linear warm-up of `warmup_iters` iterations starting at `warmup_ratio` x lr, floor
+    `min_lr_ratio` x lr (mmcv formulas: annealing_cos and the 'linear' warm-up factor
+    1 - (1 - it/warmup_iters)(1 - warmup_ratio)).  Stepped once per iteration; mmcv's default for this
+    policy anneals per EPOCH (by_epoch=True) with the same formula -- pass total_iters = epochs and
+    call step() per epoch to reproduce that."""
+
+    def __init__(self, optimizer, total_iters, warmup_iters=500, warmup_ratio=1.0 / 3, min_lr_ratio=1e-3):
+        import math
+        self._cos = math.cos
+        self._pi = math.pi
+        self.opt, self.total = optimizer, max(1, total_iters)
+        self.warmup_iters, self.warmup_ratio, self.min_lr_ratio = warmup_iters, warmup_ratio, min_lr_ratio
+        self.base = [g["lr"] for g in optimizer.param_groups]
+        self.it = 0
+
+    def lr_at(self, it, base):
+        target = base * self.min_lr_ratio
+        lr = target + 0.5 * (base - target) * (1 + self._cos(self._pi * min(it, self.total) / self.total))
+        if it < self.warmup_iters:
+            k = (1 - it / self.warmup_iters) * (1 - self.warmup_ratio)
+            lr = lr * (1 - k)
+        return lr
+
+    def step(self):
+        for g, b in zip(self.opt.param_groups, self.base):
+            g["lr"] = self.lr_at(self.it, b)
+        self.it += 1
+
+
+def fit(model, optimizer, batches, iters, scheduler=None, max_norm=35.0, log_every=50, log_path=None,
+        ckpt_path=None, ckpt_every=0, rank=0):
+    """Thin training loop (the reference delegates this to mmcv's EpochBasedRunner + hooks, which are
+    out of scope): `batches` is any iterable of forward_train kwargs; JSON-lines log of the loss
+    terms and samples/s; optional periodic checkpoints in the mmcv dictionary layout."""
+    import json
+    import time
+    from .checkpoint import save_checkpoint
+    it = 0
+    t0 = time.perf_counter()
+    log = open(log_path, "a") if (log_path and rank == 0) else None
+    while it < iters:
+        for batch in batches:
+            if scheduler is not None:
+                scheduler.step()
+            total, parts = train_step(model, optimizer, batch, max_norm)
+            it += 1
+            if log is not None and (it % log_every == 0 or it == iters):
+                rec = dict(iter=it, lr=optimizer.param_groups[0]["lr"], loss=float(total),
+                           samples_per_s_per_rank=it / (time.perf_counter() - t0),
+                           **{k: float(v) for k, v in parts.items()})
+                log.write(json.dumps(rec) + "\n"); log.flush()
+            if ckpt_path and ckpt_every and it % ckpt_every == 0 and rank == 0:
+                save_checkpoint(model, ckpt_path, optimizer, meta=dict(iter=it, epoch=0))
+            if it >= iters:
+                break
+    if log is not None:
+        log.close()
+    return it
