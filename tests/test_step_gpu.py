@@ -64,3 +64,4 @@ def test_forward_test_reports_chamfer_per_frame():
     assert set(res) == {f"frame.{i}" for i in range(7)}      # current + 6 test futures
     for v in res.values():
         assert v["count"] == 1 and np.isfinite(v["chamfer_distance"]) and v["chamfer_distance"] >= 0
+        assert np.isfinite(v["l1_error"]) and v["l1_error"] >= 0 and np.isfinite(v["absrel_error"])

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import BACKBONES, DETECTORS, NECKS, build_head
-from ..utils import e2e_predictor_utils
+from ..utils import e2e_predictor_utils, eval_utils
 
 
 @DETECTORS.register_module()
@@ -211,9 +211,8 @@ class ViDAR(nn.Module):
     @torch.no_grad()
     def forward_test(self, img_metas, img=None, gt_points=None, img_feats=None, **kwargs):
         """history BEV over all frames -> auto-regressive future BEVs -> arg-max decode -> per-frame
-        squared-L2 chamfer distance (compute_chamfer_distance_inner).  The 4d-occ ray errors
-        (utils/eval_utils.py:185-225: l1_error / absrel_error, host numpy) are a 'next' row and are
-        reported as None."""
+        squared-L2 chamfer distance (compute_chamfer_distance_inner) and the 4d-occ ray errors
+        (utils/eval_utils.py:185-225: l1_error / absrel_error)."""
         self.eval()
         num_frames = img.size(1) if img is not None else img_feats[0].size(1)
         prev_bev = self.obtain_history_bev(img, img_metas, img_feats, num_frames)
@@ -240,13 +239,17 @@ class ViDAR(nn.Module):
             tgt_pc_range=self.point_cloud_range, img_metas=cur_metas)
         ret = dict()
         for f in range(len(decode["pred_pcds"][0])):
-            cd, count = 0.0, 0
+            cd, l1, absrel, count = 0.0, 0.0, 0.0, 0
             for b in range(len(decode["pred_pcds"])):
-                v = e2e_predictor_utils.compute_chamfer_distance_inner(
-                    decode["pred_pcds"][b][f], decode["gt_pcds"][b][f], self.point_cloud_range)
-                cd += float(v)
+                pred, gt = decode["pred_pcds"][b][f], decode["gt_pcds"][b][f]
+                cd += float(e2e_predictor_utils.compute_chamfer_distance_inner(pred, gt, self.point_cloud_range))
+                if pred.shape[0] > 0:
+                    e1, e2 = eval_utils.compute_ray_errors(
+                        pred.cpu().numpy().astype(np.float64), gt.cpu().numpy().astype(np.float64),
+                        decode["origin"][b, f].cpu().numpy().astype(np.float64), pred.device)
+                    l1 += float(e1); absrel += float(e2)
                 count += 1
-            ret[f"frame.{f}"] = dict(count=count, chamfer_distance=cd, l1_error=None, absrel_error=None)
+            ret[f"frame.{f}"] = dict(count=count, chamfer_distance=cd, l1_error=l1, absrel_error=absrel)
         return [ret]
 
     def forward(self, return_loss=True, **kwargs):
