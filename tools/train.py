@@ -1,0 +1,93 @@
+"""Thin launcher (the reference: tools/train.py + tools/dist_train.sh around mmcv's runner):
+
+    python tools/train.py vidar_1_8_nusc_1future --iters 100 --work-dir work_dirs/demo
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py \
+        /path/to/released/config.py --iters 1000 --cfg-options model.supervise_all_future=False
+
+CONFIG is one of the in-repo names (vidar_amd.configs.VARIANTS) or a path to a released mmcv-style
+config file, which loads unchanged.  Data: the synthetic generator (no dataset code in scope);
+every rank draws its own samples.  DDP over RCCL, AdamW + cosine/warm-up, grad-clip 35, JSON-lines
+log, mmcv-layout checkpoints, --resume-from."""
+import argparse
+import ast
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--work-dir", default="work_dirs/run")
+    ap.add_argument("--resume-from")
+    ap.add_argument("--no-backbone", action="store_true")
+    ap.add_argument("--rays-per-frame", type=int, default=30000)
+    ap.add_argument("--samples", type=int, default=4, help="distinct synthetic samples cycled per rank")
+    ap.add_argument("--cfg-options", nargs="*", default=[], help="dotted overrides a.b=c")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    from vidar_amd import checkpoint as C
+    from vidar_amd import train as T
+    from vidar_amd.configs import VARIANTS, get_config
+    from vidar_amd.plugin.config import Config
+    from vidar_amd.synthetic import fpn_features, make_sample
+
+    rank, local, world = T.init_distributed()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(local)
+    if args.config in VARIANTS:
+        meta = get_config(args.config, with_backbone=not args.no_backbone)
+        model_cfg, opt_cfg, clip = meta["model"], meta["optimizer"], meta["grad_clip"]
+    else:
+        cfg = Config.fromfile(args.config)
+        cfg.merge_from_dict({k: ast.literal_eval(v) if v[:1] in "-0123456789[({TFN'\"" else v
+                             for k, v in (o.split("=", 1) for o in args.cfg_options)})
+        model_cfg = dict(cfg.model)
+        name = Path(args.config).stem
+        meta = get_config(name if name in VARIANTS else "vidar_1_8_nusc_1future")
+        opt_cfg = dict(lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.weight_decay)
+        clip = cfg.optimizer_config.grad_clip.max_norm
+        if args.no_backbone:
+            model_cfg.pop("img_backbone", None); model_cfg.pop("img_neck", None)
+    torch.manual_seed(args.seed); np.random.seed(args.seed + rank)
+    model = T.build_model(model_cfg).to(dev).train()
+    ddp = T.wrap_ddp(model, local)
+    opt = T.build_optimizer(model, **opt_cfg)
+    sched = T.CosineWithWarmup(opt, args.iters)
+    if args.resume_from:
+        _, it0 = C.resume(model, opt, args.resume_from, map_location=dev)
+        sched.it = it0
+
+    def sample(i):
+        metas, gt = make_sample(1000 * rank + i, queue_length=meta["queue_length"],
+                                future_frames=meta["future_frames"], rays_per_frame=args.rays_per_frame,
+                                num_cams=meta["num_cams"], img_hw=meta["img_hw"])
+        b = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)])
+        if args.no_backbone:
+            b["img_feats"] = fpn_features(i, 5, num_cams=meta["num_cams"], shapes=meta["fpn_shapes"], device=dev)
+        else:
+            g = torch.Generator().manual_seed(1000 * rank + i)
+            b["img"] = torch.randn(1, 5, meta["num_cams"], 3, *meta["img_hw"], generator=g).to(dev)
+        return b
+
+    work = Path(args.work_dir)
+    if rank == 0:
+        work.mkdir(parents=True, exist_ok=True)
+    n = T.fit(ddp, opt, [sample(i) for i in range(args.samples)], args.iters, scheduler=sched, max_norm=clip,
+              log_every=10, log_path=work / "log.jsonl", ckpt_path=work / "latest.pth",
+              ckpt_every=max(1, args.iters // 2), rank=rank)
+    if rank == 0:
+        print(f"finished {n} iterations; log: {work / 'log.jsonl'}; checkpoint: {work / 'latest.pth'}")
+
+
+if __name__ == "__main__":
+    main()
