@@ -164,3 +164,43 @@ def test_full_size_properties():
     g2 = dvxlr.get_grad_sigma(em * 2, idx, d[3], d[0])[0]
     torch.testing.assert_close(g2, g1 * 2, rtol=1e-4, atol=1e-5)
     assert abs(float(g1.sum()) - float(em.double().sum())) <= 1e-3 * float(em.double().abs().sum())
+
+
+def _nan_equal(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def test_adversarial_rays_bit_exact():
+    """integer-aligned origins / end points, axis-parallel, outside starts, zero length (NaN dir)."""
+    from test_oracle_dvr_edge import edge_case
+    from vidar_amd.third_lib import dvxlr, dvr
+    sigma, origin, points, tindex = edge_case()
+    o = O.dvxlr_render(sigma, origin, points, tindex)
+    pred, gt, dd, idx = dvxlr.render(*dev(sigma, origin, points, tindex))
+    assert _nan_equal(idx.cpu().numpy(), o[3]) and _nan_equal(gt.cpu().numpy(), o[1])
+    ok = np.isfinite(o[0])
+    close(pred.cpu().numpy()[ok], o[0][ok])
+    assert np.array_equal(np.isnan(pred.cpu().numpy()), np.isnan(o[0]))
+    of = O.render_forward(sigma, origin, points, tindex, "test")
+    pf, gf = dvr.render_forward(*dev(sigma, origin, points, tindex), [2, 4, 9, 7], "test")
+    assert _nan_equal(gf.cpu().numpy(), of[1])
+    close(pf.cpu().numpy()[ok], of[0][ok])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_snapped_volumes_bit_exact(seed):
+    """half-integer coordinates produce exact ties in the traversal order; small odd volumes."""
+    from vidar_amd.third_lib import dvxlr_v2
+    rng = np.random.default_rng(seed)
+    Z, Y, X = rng.integers(1, 7), rng.integers(1, 13), rng.integers(1, 13)
+    sigma = rng.uniform(0, 2, (1, 1, Z, Y, X)).astype(np.float32)
+    regul = rng.standard_normal(sigma.shape).astype(np.float32)
+    origin = (np.round(rng.uniform(-1, [X + 1, Y + 1, Z + 1], (1, 1, 3)) * 2) / 2).astype(np.float32)
+    pts = (np.round(rng.uniform(-4, [X + 4, Y + 4, Z + 4], (1, 40, 3)) * 2) / 2).astype(np.float32)
+    pts[0][(pts[0] == origin[0, 0]).all(1)] += 1.0
+    tindex = np.where(rng.uniform(size=(1, 40)) < 0.1, -1.0, 0.0).astype(np.float32)
+    o = O.dvxlr_render(sigma, origin, pts, tindex, regul)
+    g = dvxlr_v2.render_v2(*dev(sigma, origin, pts, tindex, regul))
+    assert np.array_equal(g[3].cpu().numpy(), o[3]) and np.array_equal(g[5].cpu().numpy(), o[5])
+    assert np.array_equal(g[1].cpu().numpy(), o[1]) and np.array_equal(g[4].cpu().numpy(), o[4])
+    close(g[0], o[0]); close(g[2], o[2])
