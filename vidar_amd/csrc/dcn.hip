@@ -50,7 +50,38 @@ __device__ __forceinline__ float sample(const float* __restrict__ im, const Bil&
   return hh * hw * v1 + hh * q.lw * v2 + q.lh * hw * v3 + q.lh * q.lw * v4;
 }
 
-// grid: (ceil(P/256), C, N)
+// A thread owns one output pixel and kCG consecutive channels: the 9 sampling footprints (index
+// arithmetic + offset / mask loads) are computed once and reused for every channel of the group.
+constexpr int kCG = 8;
+constexpr int kMaxTaps = 9;
+
+struct Foot {
+  Bil q[kMaxTaps];
+  float m[kMaxTaps];
+};
+
+__device__ __forceinline__ Foot footprints(const float* __restrict__ offset,
+                                           const float* __restrict__ mask, int n, int p, const Conv& g) {
+  const int P = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int py = p / g.Wo, px = p % g.Wo;
+  Foot f;
+#pragma unroll
+  for (int t = 0; t < kMaxTaps; ++t) {
+    if (t < K) {
+      const int i = t / g.kw, j = t % g.kw;
+      const float h = py * g.stride - g.pad + i * g.dil + offset[((size_t)n * 2 * K + 2 * t) * P + p];
+      const float w = px * g.stride - g.pad + j * g.dil + offset[((size_t)n * 2 * K + 2 * t + 1) * P + p];
+      f.q[t] = bil(h, w, g.H, g.W);
+      f.m[t] = mask[((size_t)n * K + t) * P + p];
+    } else {
+      f.q[t] = bil(-2.f, -2.f, g.H, g.W);
+      f.m[t] = 0.f;
+    }
+  }
+  return f;
+}
+
+// grid: (ceil(P/256), ceil(C/kCG), N)
 __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict__ x,
                                                          const float* __restrict__ offset,
                                                          const float* __restrict__ mask,
@@ -58,21 +89,19 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
   const int P = g.Ho * g.Wo, K = g.kh * g.kw;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
-  const int c = blockIdx.y, n = blockIdx.z;
-  const int py = p / g.Wo, px = p % g.Wo;
-  const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
-  const float* off = offset + (size_t)n * 2 * K * P + p;
-  const float* mk = mask + (size_t)n * K * P + p;
-  float* out = cols + ((size_t)n * g.C + c) * K * P + p;
-  for (int t = 0; t < K; ++t) {
-    const int i = t / g.kw, j = t % g.kw;
-    const float h = py * g.stride - g.pad + i * g.dil + off[(size_t)(2 * t) * P];
-    const float w = px * g.stride - g.pad + j * g.dil + off[(size_t)(2 * t + 1) * P];
-    out[(size_t)t * P] = sample(im, bil(h, w, g.H, g.W), g.W) * mk[(size_t)t * P];
+  const int n = blockIdx.z, c0 = blockIdx.y * kCG;
+  const Foot f = footprints(offset, mask, n, p, g);
+  for (int c = c0; c < min(c0 + kCG, g.C); ++c) {
+    const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
+    float* out = cols + ((size_t)n * g.C + c) * K * P + p;
+#pragma unroll
+    for (int t = 0; t < kMaxTaps; ++t)
+      if (t < K) out[(size_t)t * P] = sample(im, f.q[t], g.W) * f.m[t];
   }
 }
 
-// grad wrt input: scatter grad_cols * mask * corner weights (atomics); grid as im2col
+// grad wrt input: scatter grad_cols * mask * corner weights (atomics); grid as im2col.  Lanes are
+// neighbouring pixels, so a wave instruction touches only 2-3 lines (atomics cost per instruction x line).
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ grad_cols,
                                                          const float* __restrict__ offset,
                                                          const float* __restrict__ mask,
@@ -80,25 +109,24 @@ __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict
   const int P = g.Ho * g.Wo, K = g.kh * g.kw;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
-  const int c = blockIdx.y, n = blockIdx.z;
-  const int py = p / g.Wo, px = p % g.Wo;
-  float* gim = grad_x + ((size_t)n * g.C + c) * g.H * g.W;
-  const float* off = offset + (size_t)n * 2 * K * P + p;
-  const float* mk = mask + (size_t)n * K * P + p;
-  const float* gc = grad_cols + ((size_t)n * g.C + c) * K * P + p;
-  for (int t = 0; t < K; ++t) {
-    const int i = t / g.kw, j = t % g.kw;
-    const float h = py * g.stride - g.pad + i * g.dil + off[(size_t)(2 * t) * P];
-    const float w = px * g.stride - g.pad + j * g.dil + off[(size_t)(2 * t + 1) * P];
-    const Bil q = bil(h, w, g.H, g.W);
-    if (!q.in) continue;
-    const float gv = gc[(size_t)t * P] * mk[(size_t)t * P];
-    if (gv == 0.f) continue;
-    const float hh = 1.f - q.lh, hw = 1.f - q.lw;
-    if (q.t && q.l) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0, hh * hw * gv);
-    if (q.t && q.r) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0 + 1, hh * q.lw * gv);
-    if (q.b && q.l) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0, q.lh * hw * gv);
-    if (q.b && q.r) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0 + 1, q.lh * q.lw * gv);
+  const int n = blockIdx.z, c0 = blockIdx.y * kCG;
+  const Foot f = footprints(offset, mask, n, p, g);
+  for (int c = c0; c < min(c0 + kCG, g.C); ++c) {
+    float* gim = grad_x + ((size_t)n * g.C + c) * g.H * g.W;
+    const float* gc = grad_cols + ((size_t)n * g.C + c) * K * P + p;
+#pragma unroll
+    for (int t = 0; t < kMaxTaps; ++t) {
+      if (t >= K) continue;
+      const Bil& q = f.q[t];
+      if (!q.in) continue;
+      const float gv = gc[(size_t)t * P] * f.m[t];
+      if (gv == 0.f) continue;
+      const float hh = 1.f - q.lh, hw = 1.f - q.lw;
+      if (q.t && q.l) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0, hh * hw * gv);
+      if (q.t && q.r) unsafeAtomicAdd(gim + q.h0 * g.W + q.w0 + 1, hh * q.lw * gv);
+      if (q.b && q.l) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0, q.lh * hw * gv);
+      if (q.b && q.r) unsafeAtomicAdd(gim + (q.h0 + 1) * g.W + q.w0 + 1, q.lh * q.lw * gv);
+    }
   }
 }
 
@@ -155,8 +183,9 @@ int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask,
   Conv g{C, H, W, Ho, Wo, kh, kw, stride, pad, dil};
   if (dcn_bad(N, g)) return VIDAR_ERR_BAD_ARG;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(dcn_im2col_kernel, dim3((Ho * Wo + 255) / 256, C, N), dim3(256), 0,
-                     (hipStream_t)stream, x, offset, mask, cols, g);
+  if (kh * kw > kMaxTaps) return VIDAR_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dcn_im2col_kernel, dim3((Ho * Wo + 255) / 256, (C + kCG - 1) / kCG, N), dim3(256),
+                     0, (hipStream_t)stream, x, offset, mask, cols, g);
   return vidar_last_error();
 }
 
@@ -171,8 +200,9 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
   hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)N * C * H * W, s);
   if (e != hipSuccess) return (int)e;
   if (N == 0) return 0;
-  hipLaunchKernelGGL(dcn_col2im_kernel, dim3((Ho * Wo + 255) / 256, C, N), dim3(256), 0, s,
-                     grad_cols, offset, mask, grad_x, g);
+  if (kh * kw > kMaxTaps) return VIDAR_ERR_BAD_ARG;
+  hipLaunchKernelGGL(dcn_col2im_kernel, dim3((Ho * Wo + 255) / 256, (C + kCG - 1) / kCG, N), dim3(256),
+                     0, s, grad_cols, offset, mask, grad_x, g);
   hipLaunchKernelGGL(dcn_col2im_coord_kernel, dim3((Ho * Wo + 255) / 256, kh * kw, N), dim3(256), 0,
                      s, grad_cols, x, offset, mask, grad_offset, grad_mask, g);
   return vidar_last_error();
