@@ -63,9 +63,17 @@ int vidar_dvr_init_f32(const float* points, const float* tindex, float* occupanc
  * ------------------------------------------------------------------------- */
 int vidar_dvxlr_max_d(void); /* 1026, third_lib/dvxlr/dvxlr.cu:10 */
 
+/* tuning/A-B switch of the dvr / dvxlr march launches: a launch with more than `min_waves` waves of
+ * 64 rays (default 1024 = one per SIMD) ranks the rays of each 256-ray workgroup by estimated
+ * length before walking them; 0 = always, INT_MAX = never.  Results do not depend on it.
+ * Returns the previous value. */
+int vidar_dvr_set_sort_min_waves(int min_waves);
+
 /* dvxlr.render(sigma, origin, points, tindex) -> [pred_dist, gt_dist, dd_dsigma, indices]
  * third_lib/dvxlr/dvxlr.cu:160-517.
- *   dd_dsigma [N,M,1026] f32 (0-padded), indices [N,M,1026,3] f32 as (z,y,x) (0-padded). */
+ *   dd_dsigma [N,M,1026] f32 (0-padded), indices [N,M,1026,3] f32 as (z,y,x) (0-padded).
+ *   The call writes every byte of the outputs (padding included); the padded row buffers must be
+ *   8-byte aligned (VIDAR_ERR_BAD_ARG otherwise). */
 int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float* points,
                            const float* tindex, float* pred_dist, float* gt_dist, float* dd_dsigma,
                            float* indices, int N, int M, int T, int TO, int Z, int Y, int X,

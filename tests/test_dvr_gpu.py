@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
 
 
+@pytest.fixture(autouse=True, params=["plain", "ranked"])
+def march_order(request):
+    """every test runs twice: default launch, and with the rays of each workgroup ranked by
+    estimated length (what launches above 65k rays do) -- results must not depend on it."""
+    from vidar_amd._lib import lib
+    prev = lib().vidar_dvr_set_sort_min_waves(0 if request.param == "ranked" else 1 << 30)
+    yield request.param
+    lib().vidar_dvr_set_sort_min_waves(prev)
+
+
 def dev(*arrs):
     return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
 
@@ -181,6 +191,10 @@ def test_adversarial_rays_bit_exact():
     ok = np.isfinite(o[0])
     close(pred.cpu().numpy()[ok], o[0][ok])
     assert np.array_equal(np.isnan(pred.cpu().numpy()), np.isnan(o[0]))
+    ddh = dd.cpu().numpy()
+    assert np.array_equal(np.isnan(ddh), np.isnan(o[2]))       # NaN rays poison their rows like the reference
+    fin = np.isfinite(o[2])
+    close(ddh[fin], o[2][fin])
     of = O.render_forward(sigma, origin, points, tindex, "test")
     pf, gf = dvr.render_forward(*dev(sigma, origin, points, tindex), [2, 4, 9, 7], "test")
     assert _nan_equal(gf.cpu().numpy(), of[1])
@@ -204,3 +218,28 @@ def test_random_snapped_volumes_bit_exact(seed):
     assert np.array_equal(g[3].cpu().numpy(), o[3]) and np.array_equal(g[5].cpu().numpy(), o[5])
     assert np.array_equal(g[1].cpu().numpy(), o[1]) and np.array_equal(g[4].cpu().numpy(), o[4])
     close(g[0], o[0]); close(g[2], o[2])
+
+
+def test_ranked_march_is_bitwise_invisible_at_full_size():
+    """BASELINE size (5 frames x 30k rays): ranked and plain launches give identical bytes, every
+    output byte is written by the call (poisoned buffers), counts agree with render_forward."""
+    from vidar_amd._lib import lib
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvr, dvxlr, dvxlr_v2
+    sigma, origin, points, tindex = dev(*ray_set(seed=3, N=1, T=5, rays_per_frame=30000, pad=111))
+    outs = {}
+    for mode, thr in (("plain", 1 << 30), ("ranked", 0)):
+        lib().vidar_dvr_set_sort_min_waves(thr)
+        torch.empty(3 * 1024 ** 3 // 4, device="cuda").fill_(float("nan"))   # poison the allocator's blocks
+        torch.cuda.synchronize()
+        outs[mode] = (dvxlr.render(sigma, origin, points, tindex),
+                      dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma),
+                      dvr.render_forward(sigma, origin, points, tindex, [5, 16, 200, 200], "train"),
+                      dvr.render(sigma, origin, points, tindex, "l2")[:2])
+    for a, b in zip(outs["plain"], outs["ranked"]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    pred, gt, dd, idx = outs["ranked"][0]
+    assert torch.isfinite(dd).all() and torch.isfinite(idx).all()
+    valid = tindex >= 0
+    assert bool((pred[~valid] == -1).all()) and bool((dd[~valid] == 0).all())

@@ -1,0 +1,116 @@
+"""vidar_amd/csrc/dvr_march.h (the per-lane traversal + integrator of every dvr / dvxlr kernel)
+compiled for the host and compared with the oracle: bit-exact voxel lists, counts and dt, values to
+fp32 round-off.  Lets the traversal logic be checked without a GPU; the GPU tests remain the parity
+tests proper (tests/test_dvr_gpu.py)."""
+import ctypes
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import dvr as O
+from dvr_cases import CASES, case
+from test_oracle_dvr_edge import edge_case as adversarial_case
+
+ROOT = Path(__file__).resolve().parents[1]
+L = 1026
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    so = tmp_path_factory.mktemp("march_host") / "libmarch_host.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                    f"-I{ROOT / 'vidar_amd' / 'csrc'}", str(ROOT / "tests" / "march_host.cpp"),
+                    "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _prep(sigma, origin, points, tindex):
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    sigma, origin, points, tindex = f(sigma), f(origin), f(points), f(tindex)
+    N, T, Z, Y, X = sigma.shape
+    return sigma, origin, points, tindex, (N, points.shape[1], T, origin.shape[1], Z, Y, X)
+
+
+def snapped_case(seed):
+    """half-integer coordinates produce exact ties in the traversal order; small odd volumes."""
+    rng = np.random.default_rng(seed)
+    Z, Y, X = rng.integers(1, 7), rng.integers(1, 13), rng.integers(1, 13)
+    sigma = rng.uniform(0, 2, (1, 1, Z, Y, X)).astype(np.float32)
+    origin = (np.round(rng.uniform(-1, [X + 1, Y + 1, Z + 1], (1, 1, 3)) * 2) / 2).astype(np.float32)
+    pts = (np.round(rng.uniform(-4, [X + 4, Y + 4, Z + 4], (1, 40, 3)) * 2) / 2).astype(np.float32)
+    pts[0][(pts[0] == origin[0, 0]).all(1)] += 1.0
+    tindex = np.where(rng.uniform(size=(1, 40)) < 0.1, -1.0, 0.0).astype(np.float32)
+    return sigma, origin, pts, tindex
+
+
+def _cases():
+    out = [(n, lambda n=n: case(n)) for n in CASES]
+    out.append(("adversarial", adversarial_case))
+    out += [(f"snapped{s}", lambda s=s: snapped_case(s)) for s in range(100, 124)]
+    return out
+
+
+@pytest.mark.parametrize("name,make", _cases(), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("v2", [False, True])
+def test_dvxlr_rows(host, name, make, v2):
+    sigma, origin, points, tindex, dims = _prep(*make())
+    N, M = dims[0], dims[1]
+    reg = (np.random.default_rng(7).random(sigma.shape, dtype=np.float32)) if v2 else None
+    ref = O.dvxlr_render(sigma, origin, points, tindex, reg)
+    pred = np.empty((N, M), np.float32); gt = np.empty((N, M), np.float32)
+    poison = lambda *shape: np.full(shape, 12345.0, np.float32)     # the call owns every byte
+    dd = poison(N, M, L); idx = poison(N, M, L, 3); rp = poison(N, M, L); ind = poison(N, M, L)
+    est = np.zeros((N, M), np.int32)
+    rc = host.host_dvxlr_render(_p(sigma), _p(reg) if v2 else None, _p(origin), _p(points), _p(tindex),
+                                _p(pred), _p(gt), _p(dd), _p(idx), _p(rp), _p(ind), _p(est), *dims)
+    assert rc == 0
+    np.testing.assert_array_equal(idx, ref[3])                     # voxel lists: bit-exact
+    np.testing.assert_allclose(dd, ref[2], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(pred, ref[0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(gt, ref[1])
+    if v2:
+        np.testing.assert_array_equal(rp, ref[4])
+        np.testing.assert_array_equal(ind, ref[5])
+    if M:
+        # the ranking key tracks the true number of samples (only a heuristic, but it should be a
+        # useful one): rank correlation on the valid rays
+        cnt = (ref[3] != 0).any(-1).sum(-1).ravel().astype(np.float64)
+        e = est.ravel().astype(np.float64)
+        ok = cnt > 0
+        if ok.sum() > 100 and cnt[ok].std() > 0 and e[ok].std() > 0:
+            assert np.corrcoef(cnt[ok], e[ok])[0, 1] > 0.8
+
+
+@pytest.mark.parametrize("name,make", _cases(), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("phase", ["test", "train"])
+def test_dvr_render_forward(host, name, make, phase):
+    sigma, origin, points, tindex, dims = _prep(*make())
+    N, M = dims[0], dims[1]
+    ref = O.render_forward(sigma, origin, points, tindex, phase)
+    pred = np.empty((N, M), np.float32); gt = np.empty((N, M), np.float32)
+    assert host.host_dvr_render_forward(_p(sigma), _p(origin), _p(points), _p(tindex), _p(pred), _p(gt),
+                                        *dims, O.PHASE[phase]) == 0
+    np.testing.assert_allclose(pred, ref[0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(gt, ref[1])
+
+
+@pytest.mark.parametrize("name,make", _cases(), ids=[c[0] for c in _cases()])
+@pytest.mark.parametrize("loss", ["l1", "l2", "absrel"])
+def test_dvr_render(host, name, make, loss):
+    sigma, origin, points, tindex, dims = _prep(*make())
+    N, M = dims[0], dims[1]
+    ref = O.render(sigma, origin, points, tindex, loss)
+    pred = np.empty((N, M), np.float32); gt = np.empty((N, M), np.float32)
+    grad = np.empty(sigma.shape, np.float64)
+    assert host.host_dvr_render(_p(sigma), _p(origin), _p(points), _p(tindex), _p(pred), _p(gt), _p(grad),
+                                *dims, O.LOSS[loss]) == 0
+    np.testing.assert_allclose(pred, ref[0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(gt, ref[1])
+    scale = max(1.0, float(np.abs(ref[2]).max()))
+    np.testing.assert_allclose(grad, ref[2], rtol=1e-4, atol=1e-4 * scale)
