@@ -68,6 +68,10 @@ int vidar_dvxlr_max_d(void); /* 1026, third_lib/dvxlr/dvxlr.cu:10 */
  * length before walking them; 0 = always, INT_MAX = never.  Results do not depend on it.
  * Returns the previous value. */
 int vidar_dvr_set_sort_min_waves(int min_waves);
+/* tuning/A-B switch of dvxlr.render / render_v2: 0 = the finish pass pads the [1026] rows itself,
+ * 1 = one device fill ahead of the march, the finish pass only touches the live prefixes.
+ * Results do not depend on it.  Returns the previous value. */
+int vidar_dvxlr_set_pad_mode(int mode);
 
 /* dvxlr.render(sigma, origin, points, tindex) -> [pred_dist, gt_dist, dd_dsigma, indices]
  * third_lib/dvxlr/dvxlr.cu:160-517.

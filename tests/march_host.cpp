@@ -91,29 +91,31 @@ int host_dvxlr_render(const float* sigma, const float* sigma_regul, const float*
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < M; ++c) {
       est_steps[(size_t)n * M + c] = estimate_steps(load_ray(origin, points, tindex, n, c, M, g), g);
-      dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices, n, c, M, g);
+      dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g);
     }
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < M; ++c) {
       const size_t row = (size_t)n * M + c;
       float* ddr = dd_dsigma + row * L;
       float* idr = indices + row * L * 3;
-      const float stash = idr[2];
-      const int cnt = (int)fabsf(stash);
-      const int ks = cnt > 0 ? (int)ddr[cnt - 1] : -1;
+      int cnt, ks;
+      bool nan_tail;
+      decode_stash(idr[2], cnt, ks, nan_tail);
       const float* reg = nullptr;
       if (sigma_regul && cnt > 0) {
         const long ti = (long)tindex[row];
         reg = sigma_regul + ((size_t)n * T + (T == 1 ? 0 : ti)) * vol;
       }
-      double R = (stash < 0.f) ? (double)NAN : 0.0;
+      double R = nan_tail ? (double)NAN : 0.0;
+      float w_above = 0.f;                     // W_k lives in sample k+1's slot
       for (int k = cnt - 1; k >= 0; --k) {
-        if (k < cnt - 1) R += (double)ddr[k];
-        const float dtk = idr[3 * k + 0];
-        const int vid = (int)idr[3 * k + 1];
+        const Parked p = reinterpret_cast<const Parked*>(idr)[k];
+        if (k < cnt - 1) R += (double)w_above;
+        w_above = p.w_prev;
+        const int vid = (int)p.vid;
         const int zy = vid / X, x = vid - zy * X;
         const int z = zy / Y, y = zy - z * Y;
-        ddr[k] = (float)(-(double)dtk * R);
+        ddr[k] = (float)(-(double)p.dt * R);
         idr[3 * k + 0] = (float)z; idr[3 * k + 1] = (float)y; idr[3 * k + 2] = (float)x;
         if (sigma_regul) {
           ray_pred[row * L + k] = reg[vid];

@@ -13,14 +13,17 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
 
 
-@pytest.fixture(autouse=True, params=["plain", "ranked"])
+@pytest.fixture(autouse=True, params=["plain", "ranked", "ranked-prefill"])
 def march_order(request):
-    """every test runs twice: default launch, and with the rays of each workgroup ranked by
-    estimated length (what launches above 65k rays do) -- results must not depend on it."""
+    """every test runs under each launch variant: default, with the rays of each workgroup ranked
+    by estimated length (what launches above 65k rays do), and with the device-fill-first padding
+    of dvxlr.render -- results must not depend on it."""
     from vidar_amd._lib import lib
-    prev = lib().vidar_dvr_set_sort_min_waves(0 if request.param == "ranked" else 1 << 30)
+    prev = lib().vidar_dvr_set_sort_min_waves(1 << 30 if request.param == "plain" else 0)
+    prev_pad = lib().vidar_dvxlr_set_pad_mode(1 if request.param.endswith("prefill") else 0)
     yield request.param
     lib().vidar_dvr_set_sort_min_waves(prev)
+    lib().vidar_dvxlr_set_pad_mode(prev_pad)
 
 
 def dev(*arrs):

@@ -32,6 +32,9 @@ def report(name, ms, nbytes=None, **kw):
     print(json.dumps(d), flush=True)
 
 
+PAD_MODE_DEFAULT = 1
+
+
 def bench_dvr(which):
     buf = torch.empty(2478800000 // 4, device="cuda")
     ms = timeit(lambda: buf.zero_())
@@ -42,7 +45,19 @@ def bench_dvr(which):
     del buf, src
     from vidar_amd.synthetic import ray_set
     from vidar_amd.third_lib import dvr, dvxlr, dvxlr_v2
+    from vidar_amd._lib import lib
     t = lambda a: torch.from_numpy(a).cuda()
+    # A/B of the launch variants (results are identical, tests/test_dvr_gpu.py)
+    sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=5, rays_per_frame=30000))
+    for pad_mode in (0, 1):
+        for thr, order in ((1 << 30, "plain"), (0, "ranked")):
+            lib().vidar_dvxlr_set_pad_mode(pad_mode); lib().vidar_dvr_set_sort_min_waves(thr)
+            ms = timeit(lambda: dvxlr.render(sigma, origin, points, tindex))
+            ms2 = timeit(lambda: dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma))
+            ms3 = timeit(lambda: dvr.render_forward(sigma, origin, points, tindex, [5, 16, 200, 200], "train"))
+            report(f"A/B pad_mode={pad_mode} order={order} M=150000", ms, render_v2_ms=round(ms2, 4),
+                   render_forward_ms=round(ms3, 4))
+    lib().vidar_dvxlr_set_pad_mode(PAD_MODE_DEFAULT); lib().vidar_dvr_set_sort_min_waves(1024)
     for T, rpf in ((1, 30000), (5, 30000)):
         sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=T, rays_per_frame=rpf))
         N, M = tindex.shape

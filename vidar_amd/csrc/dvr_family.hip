@@ -69,6 +69,7 @@ __device__ __forceinline__ int pick_ray(const float* __restrict__ origin,
 }
 
 int g_sort_min_waves = kSimds;
+int g_dvxlr_pad_mode = 1;   // 0: the finish pass pads the rows; 1: device fill first, finish pass only fixes the live prefixes
 inline bool sort_rays(int N, int M) {
   return (long)N * ((M + kWave - 1) / kWave) > (long)g_sort_min_waves;
 }
@@ -151,11 +152,9 @@ __global__ __launch_bounds__(kBlock) void dvr_render_kernel(
 // ----------------------------------------------------------------------------------------------
 // dvxlr.render / dvxlr_v2.render_v2: two launches, no scratch, every output byte written once.
 //
-//  1. march (issue bound, lane per ray): while a lane walks its ray it parks (W_{k-1}, dt_k, voxel
-//     id) inside the ray's own output rows (RowStager, dvr_march.h) and leaves three scalars in
-//     slots of the row that staging does not use:
-//         idx_row[2]        <- +-count   (negative: the ray's distances are NaN, see `tail`)
-//         dd_row[count-1]   <- k_surface (v2 indicator position, -1 if none)
+//  1. march (issue bound, lane per ray): while a lane walks its ray it parks (dt_k, voxel id,
+//     W_{k-1}) as one 12-byte store per sample inside the ray's own `indices` row (RowStager,
+//     dvr_march.h); the unused W slot of sample 0 receives count / k_surface / NaN flag.
 //  2. finish (HBM bound, wave per ray, coalesced): a reverse wave scan turns W into the suffix sums
 //     R_k, dd_dsigma[k] = -dt_k R_k, (z, y, x) are unpacked, the v2 extras are gathered and the
 //     rest of the API-mandated [1026] rows is padded -- the padding is 95 % of the bytes, and a
@@ -166,16 +165,16 @@ template <int kBlock>
 __global__ __launch_bounds__(kBlock) void dvxlr_march_kernel(
     const float* __restrict__ sigma, const float* __restrict__ origin,
     const float* __restrict__ points, const float* __restrict__ tindex,
-    float* __restrict__ pred_dist, float* __restrict__ gt_dist, float* __restrict__ dd_dsigma,
-    float* __restrict__ indices, int M, Vol g) {
+    float* __restrict__ pred_dist, float* __restrict__ gt_dist, float* __restrict__ indices, int M,
+    Vol g) {
   const int n = blockIdx.y;
   const int c = pick_ray<kBlock>(origin, points, tindex, n, M, g);
   if (c >= M) return;
-  dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices, n, c, M, g);
+  dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g);
 }
 
 // grid: (ceil(M/4), N), 256 threads = 4 rays.  Rows are 8-byte aligned (1026 floats, aligned base).
-template <bool V2>
+template <bool V2, bool PAD>
 __global__ __launch_bounds__(256) void dvxlr_finish_kernel(
     const float* __restrict__ sigma_regul, const float* __restrict__ tindex,
     float* __restrict__ dd_dsigma, float* __restrict__ indices, float* __restrict__ ray_pred,
@@ -191,27 +190,27 @@ __global__ __launch_bounds__(256) void dvxlr_finish_kernel(
   float* rpr = V2 ? ray_pred + row * L : nullptr;
   float* inr = V2 ? indicator + row * L : nullptr;
 
-  const float stash = idr[2];
-  const int cnt = (int)fabsf(stash);
-  const int ks = cnt > 0 ? (int)ddr[cnt - 1] : -1;
+  int cnt, ks;
+  bool nan_tail;
+  decode_stash(idr[2], cnt, ks, nan_tail);
   const float* reg = nullptr;
   if (V2 && cnt > 0) {
     const long ti = (long)tindex[row];          // a ray with samples has a valid time index
     reg = sigma_regul + ((size_t)n * g.T + (g.T == 1 ? 0 : ti)) * ((size_t)g.Z * g.Y * g.X);
   }
 
-  double carry = (stash < 0.f) ? (double)NAN : 0.0;
+  // chunks of 64 samples from the far end; a lane only touches the slots of its own sample.
+  // W_k sits in sample k+1's slot: neighbour lane, or lane 0 of the chunk handled just before.
+  double carry = nan_tail ? (double)NAN : 0.0;
+  float w_above = 0.f;
   for (int base = cnt > 0 ? ((cnt - 1) / kWave) * kWave : -1; base >= 0; base -= kWave) {
     const int k = base + lane;
-    // lane k only touches its own slots (dd[k] holds W_k, idx[3k..3k+2]); the stash slots
-    // (dd[cnt-1], idx[2]) were read above and are overwritten with final values here
-    double sfx = (k < cnt - 1) ? (double)ddr[k] : 0.0;
-    float dtk = 0.f;
-    int vid = 0;
-    if (k < cnt) {
-      dtk = idr[3 * k + 0];
-      vid = (int)idr[3 * k + 1];
-    }
+    Parked p{0.f, 0.f, 0.f};
+    if (k < cnt) p = reinterpret_cast<const Parked*>(idr)[k];
+    float w = __shfl_down(p.w_prev, 1, kWave);
+    if (lane == kWave - 1) w = w_above;
+    w_above = __shfl(p.w_prev, 0, kWave);
+    double sfx = (k < cnt - 1) ? (double)w : 0.0;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
       const double t = __shfl_down(sfx, off, kWave);
@@ -220,9 +219,10 @@ __global__ __launch_bounds__(256) void dvxlr_finish_kernel(
     const double R = sfx + carry;
     carry += __shfl(sfx, 0, kWave);
     if (k < cnt) {
+      const int vid = (int)p.vid;
       const int zy = vid / g.X, x = vid - zy * g.X;
       const int z = zy / g.Y, y = zy - z * g.Y;
-      ddr[k] = (float)(-(double)dtk * R);
+      ddr[k] = (float)(-(double)p.dt * R);
       idr[3 * k + 0] = (float)z;
       idr[3 * k + 1] = (float)y;
       idr[3 * k + 2] = (float)x;
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(256) void dvxlr_finish_kernel(
     }
   }
 
+  if (!PAD) return;
   // padding: one odd element if needed, then 8-byte stores
   const float2 zero2 = make_float2(0.f, 0.f), neg2 = make_float2(-1.f, -1.f);
   if ((cnt & 1) && lane == 0 && cnt < L) {
@@ -327,6 +328,11 @@ inline bool bad_dims(int N, int M, int T, int Z, int Y, int X) {
 extern "C" {
 
 int vidar_dvr_max_d(void) { return kDvrMaxD; }
+int vidar_dvxlr_set_pad_mode(int mode) {
+  const int prev = g_dvxlr_pad_mode;
+  g_dvxlr_pad_mode = mode ? 1 : 0;
+  return prev;
+}
 int vidar_dvr_set_sort_min_waves(int min_waves) {
   const int prev = g_sort_min_waves;
   g_sort_min_waves = min_waves < 0 ? 0 : min_waves;
@@ -402,20 +408,30 @@ static int dvxlr_render_launch(bool v2, const float* sigma, const float* sigma_r
     return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
+  if (g_dvxlr_pad_mode != 0) {
+    const size_t rows = (size_t)N * M * kDvxlrMaxD;
+    hipError_t e = hipMemsetAsync(dd_dsigma, 0, rows * sizeof(float), s_);
+    if (e == hipSuccess) e = hipMemsetAsync(indices, 0, rows * 3 * sizeof(float), s_);
+    if (v2 && e == hipSuccess) e = hipMemsetAsync(ray_pred, 0, rows * sizeof(float), s_);
+    if (v2 && e == hipSuccess)
+      e = hipMemsetD32Async((hipDeviceptr_t)indicator, 0xBF800000 /* -1.0f */, rows, s_);
+    if (e != hipSuccess) return (int)e;
+  }
   if (sort_rays(N, M))
     hipLaunchKernelGGL(dvxlr_march_kernel<kSortBlock>, dim3((M + kSortBlock - 1) / kSortBlock, N),
                        dim3(kSortBlock), 0, s_, sigma, origin, points, tindex, pred_dist, gt_dist,
-                       dd_dsigma, indices, M, g);
+                       indices, M, g);
   else
     hipLaunchKernelGGL(dvxlr_march_kernel<kWave>, dim3((M + kWave - 1) / kWave, N), dim3(kWave), 0, s_,
-                       sigma, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices, M, g);
+                       sigma, origin, points, tindex, pred_dist, gt_dist, indices, M, g);
   const dim3 fgrid((M + 3) / 4, N);
-  if (v2)
-    hipLaunchKernelGGL(dvxlr_finish_kernel<true>, fgrid, dim3(256), 0, s_, sigma_regul, tindex,
-                       dd_dsigma, indices, ray_pred, indicator, M, g);
-  else
-    hipLaunchKernelGGL(dvxlr_finish_kernel<false>, fgrid, dim3(256), 0, s_, sigma_regul, tindex,
-                       dd_dsigma, indices, ray_pred, indicator, M, g);
+  const bool pad = (g_dvxlr_pad_mode == 0);
+#define VIDAR_FINISH(V2_, PAD_)                                                                      \
+  hipLaunchKernelGGL((dvxlr_finish_kernel<V2_, PAD_>), fgrid, dim3(256), 0, s_, sigma_regul, tindex, \
+                     dd_dsigma, indices, ray_pred, indicator, M, g)
+  if (v2) { if (pad) VIDAR_FINISH(true, true); else VIDAR_FINISH(true, false); }
+  else    { if (pad) VIDAR_FINISH(false, true); else VIDAR_FINISH(false, false); }
+#undef VIDAR_FINISH
   return vidar_last_error();
 }
 

@@ -201,42 +201,56 @@ struct NoEmit {
   VIDAR_DEV void commit(int, int, double, double, double, double) {}
 };
 
-// dvxlr staging: while a lane walks its ray it parks, inside the ray's own output rows,
-//   dd_row[k-1]   <- W_{k-1} (fp32)     idx_row[3k+0] <- dt_k (fp32)
-//   idx_row[3k+1] <- linear voxel id, exact in fp32 below 2^24 voxels per slice
+// dvxlr staging: while a lane walks its ray it parks each sample in the ray's own `indices` row
+// (three floats per sample, ONE 12-byte store):
+//   idx_row[3k+0] <- dt_k    idx_row[3k+1] <- linear voxel id (exact in fp32 below 2^24 voxels)
+//   idx_row[3k+2] <- W_{k-1} (k >= 1)
+// The k = 0 slot idx_row[2] has no W and receives the per-ray scalars the finish pass needs
+// (encode_stash).  The dd_dsigma row is not touched by the march.
+struct Parked {
+  float dt, vid, w_prev;
+};
+
 struct RowStager {
-  float* __restrict__ dd;   // &dd_row[k] for the next commit
-  float* __restrict__ idx;  // &idx_row[3k]
+  Parked* __restrict__ slot;  // &idx_row[3k] for the next commit
   double true_len;
   int k_surface = -1;
   VIDAR_DEV void commit(int k, int vid, double d, double dt, double, double w_prev) {
-    if (k > 0) dd[-1] = (float)w_prev;
-    ++dd;
-    idx[0] = (float)dt;
-    idx[1] = (float)vid;
-    idx += 3;
+    Parked p;
+    p.dt = (float)dt;
+    p.vid = (float)vid;
+    p.w_prev = (float)w_prev;
+    *slot = p;
+    ++slot;
     if (k_surface < 0 && d >= true_len) k_surface = k;    // dvxlr_v2.cu:408-424
   }
 };
 
-// dvxlr / dvxlr_v2 march of ray c of sample n (launch 1 of dvxlr.render, see dvr_family.hip): parks
-// the samples in the ray's rows and leaves the scalars the finish pass needs in slots staging does
-// not use:  idx_row[2] <- +-count (negative: NaN distances),  dd_row[count-1] <- k_surface.
+// count in [0, 1026], k_surface in [-1, 1025], nan_tail: +-(count + 2048 (k_surface + 1)), exact in fp32
+VIDAR_DEV float encode_stash(int count, int k_surface, bool nan_tail) {
+  const float v = (float)(count + 2048 * (k_surface + 1));
+  return nan_tail ? -v : v;
+}
+VIDAR_DEV void decode_stash(float stash, int& count, int& k_surface, bool& nan_tail) {
+  nan_tail = stash < 0.f;
+  const int v = (int)fabsf(stash);
+  count = v & 2047;
+  k_surface = (v >> 11) - 1;
+}
+
+// dvxlr / dvxlr_v2 march of ray c of sample n (launch 1 of dvxlr.render, see dvr_family.hip).
 VIDAR_DEV void dvxlr_march_ray(const float* __restrict__ sigma, const float* __restrict__ origin,
                                const float* __restrict__ points, const float* __restrict__ tindex,
                                float* __restrict__ pred_dist, float* __restrict__ gt_dist,
-                               float* __restrict__ dd_dsigma, float* __restrict__ indices, int n, int c,
-                               int M, const Vol& g) {
+                               float* __restrict__ indices, int n, int c, int M, const Vol& g) {
   constexpr int L = kDvxlrMaxD;
   const size_t row = (size_t)n * M + c;
-  float* ddr = dd_dsigma + row * L;
   float* idr = indices + row * L * 3;
-  float pred = -1.f, gt = -1.f, stash_count = 0.f;
+  float pred = -1.f, gt = -1.f, stash = 0.f;
   const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
   if (r.valid) {
     RowStager st;
-    st.dd = ddr;
-    st.idx = idr;
+    st.slot = reinterpret_cast<Parked*>(idr);
     {
       const double rx = r.xe - r.xo, ry = r.ye - r.yo, rz = r.ze - r.zo;
       st.true_len = sqrt(rx * rx + ry * ry + rz * rz);
@@ -251,11 +265,10 @@ VIDAR_DEV void dvxlr_march_ray(const float* __restrict__ sigma, const float* __r
       // the reference's (max_d - d_last) p_out term (dvxlr.cu:412-439) is 0, or NaN when the
       // distances are NaN (zero-length ray): such a ray poisons its whole row
       const double tail = a.dprev - a.dprev;
-      stash_count = (tail == tail) ? (float)a.k : -(float)a.k;
-      ddr[a.k - 1] = (float)st.k_surface;
+      stash = encode_stash(a.k, st.k_surface, !(tail == tail));
     }
   }
-  idr[2] = stash_count;
+  idr[2] = stash;
   pred_dist[row] = pred;
   gt_dist[row] = gt;
 }
