@@ -148,8 +148,10 @@ def main():
         imgs = synthetic_images(200 + rank, cfg["queue_length"] + 1, cfg["num_cams"], cfg["img_hw"], dev)
         batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)], img=imgs)
 
+    grouped = dist.is_available() and dist.is_initialized()
+
     def sync():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +169,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _hip().vidar_marker(2, None)
     TIMER.enabled = False
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -204,7 +206,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
             out["cpu_baseline"]["host_cores"] = os.cpu_count()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -63,7 +63,9 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # VIDAR_FORCE_DDP=1: also form a 1-rank group (exercises RCCL + the DDP reducer on a 1-GPU box)
+    forced = os.environ.get("VIDAR_FORCE_DDP") == "1" and "RANK" in os.environ
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
@@ -73,7 +75,9 @@ def init_distributed():
 
 
 def wrap_ddp(model, local_rank, bucket_cap_mb=100):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return model
+    if dist.get_world_size() == 1 and os.environ.get("VIDAR_FORCE_DDP") != "1":
         return model
     kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
               find_unused_parameters=False)
