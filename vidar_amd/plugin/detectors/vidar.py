@@ -9,6 +9,7 @@ package can build; the hot-path bench feeds FPN feature pyramids directly throug
 from __future__ import annotations
 
 import copy
+import os
 
 import numpy as np
 import torch
@@ -50,6 +51,8 @@ class ViDAR(nn.Module):
         self.random_drop_prev_start_idx = random_drop_prev_start_idx
         self.random_drop_prev_end_idx = random_drop_prev_end_idx
         self.supervise_all_future = supervise_all_future
+        self._submission = _submission
+        self._submission_path = _submission_path
         if self.only_train_cur_frame:               # vidar.py:109-115
             del self.future_pred_head.transformer
             del self.future_pred_head.bev_embedding
@@ -248,9 +251,20 @@ class ViDAR(nn.Module):
                         pred.cpu().numpy().astype(np.float64), gt.cpu().numpy().astype(np.float64),
                         decode["origin"][b, f].cpu().numpy().astype(np.float64), pred.device)
                     l1 += float(e1); absrel += float(e2)
+                if self._submission and f > 0:      # frame 0 is the current frame (vidar.py:491-494)
+                    self._save_prediction(pred, cur_metas[b], f)
                 count += 1
             ret[f"frame.{f}"] = dict(count=count, chamfer_distance=cd, l1_error=l1, absrel_error=absrel)
         return [ret]
+
+    def _save_prediction(self, pred_pcd, img_meta, frame_idx):
+        """One text file per (sample, future frame): `<sample_idx>_<frame>.txt`, one predicted ray
+        depth per line, '%f' formatted (vidar.py:503-519)."""
+        os.makedirs(self._submission_path, exist_ok=True)
+        name = os.path.join(self._submission_path, f"{img_meta['sample_idx']}_{frame_idx}.txt")
+        depth = torch.sqrt((pred_pcd ** 2).sum(1)).cpu().numpy()
+        with open(name, "w") as f:
+            f.write("".join("%f\n" % d for d in depth))
 
     def forward(self, return_loss=True, **kwargs):
         if return_loss:

@@ -119,7 +119,8 @@ def make_sample(seed=0, queue_length=4, future_frames=2, rays_per_frame=30000, i
                  img_shape=[(img_hw[0], img_hw[1], 3)] * num_cams, can_bus=can_bus,
                  lidar2global_rotation=poses[k][:3, :3].copy(),
                  prev_bev_exists=bool(k > 0 or first_has_prev),
-                 ref_lidar_to_cur_lidar=ref2cur[k], aug_param=None)
+                 ref_lidar_to_cur_lidar=ref2cur[k], aug_param=None,
+                 sample_idx=f"synthetic{seed:06d}", scene_token=f"scene{seed:06d}")
         metas.append(m)
     fut = [ref + j for j in range(future_frames + 1)]
     metas[ref].update(
