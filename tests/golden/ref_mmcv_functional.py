@@ -1,0 +1,276 @@
+"""A FUNCTIONAL stand-in for the few mmcv-full 1.4.0 / mmdet 2.14 symbols the reference's
+transformer stack needs, so that the reference's OWN Python modules (SpatialCrossAttention,
+TemporalSelfAttention, BEVFormerEncoder / CustomBEVFormerEncoder / BEVFormerLayerV2,
+PerceptionTransformer, PredictionDecoder, PredictionTransformer ...) can be imported from
+/root/reference in this container, built from the released config dicts and run on CPU to produce
+golden vectors (tests/golden/make_transformer_golden.py).
+
+mmcv / mmdet / torchvision are not installable here.  Everything in this file is third-party
+behaviour restated from memory ([3P], "parity unpinned" for these pieces): registries and builders,
+BaseModule, FFN, LayerNorm builder, the pure-PyTorch deformable-attention formula and
+torchvision's `rotate`.  None of the reference's own arithmetic lives here.
+Used only by the golden generators; never imported by the product or by the tests."""
+import copy
+import importlib
+import math
+import sys
+import types
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = Path("/root/reference")
+PLUGIN = REF / "projects/mmdet3d_plugin"
+
+
+# ------------------------------------------------------------------------------------ registry
+class Registry:
+    def __init__(self, name):
+        self.name = name
+        self.module_dict = {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def deco(cls):
+            self.module_dict[name or cls.__name__] = cls
+            return cls
+        return deco(module) if module is not None else deco
+
+    def get(self, key):
+        return self.module_dict.get(key)
+
+    def build(self, cfg, default_args=None):
+        return build_from_cfg(cfg, self, default_args)
+
+
+def build_from_cfg(cfg, registry, default_args=None):
+    if cfg is None:
+        return None
+    args = dict(cfg)
+    if default_args:
+        for k, v in default_args.items():
+            args.setdefault(k, v)
+    typ = args.pop("type")
+    cls = registry.get(typ) if isinstance(typ, str) else typ
+    if cls is None:
+        raise KeyError(f"{typ} is not in the {registry.name} registry")
+    return cls(**args)
+
+
+class ConfigDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+# ------------------------------------------------------------------------------------ modules
+class BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+    def init_weights(self):
+        pass
+
+
+class ModuleList(nn.ModuleList):
+    def __init__(self, modules=None, init_cfg=None):
+        super().__init__(modules)
+
+
+class Sequential(nn.Sequential):
+    def __init__(self, *args, init_cfg=None):
+        super().__init__(*args)
+
+
+def xavier_init(module, gain=1, bias=0, distribution="normal"):
+    """[3P] mmcv: acts on the module itself only (a Sequential or None is left untouched)."""
+    if getattr(module, "weight", None) is not None:
+        (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(module.weight, gain=gain)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    if getattr(module, "weight", None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, "bias", None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def build_norm_layer(cfg, num_features, postfix=""):
+    assert cfg["type"] == "LN"
+    return "ln" + str(postfix), nn.LayerNorm(num_features)
+
+
+def build_activation_layer(cfg):
+    cfg = dict(cfg)
+    return {"ReLU": nn.ReLU, "GELU": nn.GELU}[cfg.pop("type")](**cfg)
+
+
+ATTENTION = Registry("attention")
+FEEDFORWARD_NETWORK = Registry("feed-forward network")
+POSITIONAL_ENCODING = Registry("position encoding")
+TRANSFORMER_LAYER = Registry("transformerLayer")
+TRANSFORMER_LAYER_SEQUENCE = Registry("transformer-layers sequence")
+TRANSFORMER = Registry("Transformer")
+HEADS = Registry("head")
+DETECTORS = Registry("detector")
+
+
+@FEEDFORWARD_NETWORK.register_module()
+class FFN(BaseModule):
+    """[3P] mmcv 1.4.0 FFN: (Linear-act-Dropout) x (num_fcs-1), Linear, Dropout, + identity."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type="ReLU", inplace=True), ffn_drop=0.0, dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        layers, in_ch = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(Sequential(nn.Linear(in_ch, feedforward_channels), build_activation_layer(act_cfg),
+                                     nn.Dropout(ffn_drop)))
+            in_ch = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = Sequential(*layers)
+        self.dropout_layer = nn.Identity()
+        self.add_identity = add_identity
+        self.embed_dims = embed_dims
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+class TransformerLayerSequence(BaseModule):
+    """[3P] mmcv 1.4.0: `num_layers` copies of `transformerlayers` built through TRANSFORMER_LAYER."""
+
+    def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        self.num_layers = num_layers
+        self.layers = ModuleList()
+        for i in range(num_layers):
+            self.layers.append(build_from_cfg(transformerlayers[i], TRANSFORMER_LAYER))
+        self.embed_dims = self.layers[0].embed_dims
+        self.pre_norm = self.layers[0].pre_norm
+
+
+def multi_scale_deformable_attn_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
+    """[3P] mmcv 1.4.0 pure-PyTorch formula: per level grid_sample(bilinear, zeros,
+    align_corners=False) of value_l [B*H, C, h, w] at 2*loc-1, weighted sum over levels and points."""
+    bs, _, num_heads, embed_dims = value.shape
+    _, num_queries, num_heads, num_levels, num_points, _ = sampling_locations.shape
+    value_list = value.split([int(h) * int(w) for h, w in value_spatial_shapes], dim=1)
+    grids = 2 * sampling_locations - 1
+    sampled = []
+    for lvl, (h, w) in enumerate(value_spatial_shapes):
+        v = value_list[lvl].flatten(2).transpose(1, 2).reshape(bs * num_heads, embed_dims, int(h), int(w))
+        g = grids[:, :, :, lvl].transpose(1, 2).flatten(0, 1)
+        sampled.append(F.grid_sample(v, g, mode="bilinear", padding_mode="zeros", align_corners=False))
+    w_ = attention_weights.transpose(1, 2).reshape(bs * num_heads, 1, num_queries, num_levels * num_points)
+    out = (torch.stack(sampled, dim=-2).flatten(-2) * w_).sum(-1).view(bs, num_heads * embed_dims, num_queries)
+    return out.transpose(1, 2).contiguous()
+
+
+def rotate(img, angle, center=None, **kw):
+    """[3P] torchvision 0.11 `rotate` on a [C,H,W] tensor: nearest interpolation, no expand, zero
+    fill, counter-clockwise `angle` (degrees) about `center` (x, y) in pixels."""
+    C, H, W = img.shape
+    cx, cy = (center if center is not None else ((W - 1) * 0.5 + 0.5, (H - 1) * 0.5 + 0.5))
+    # torchvision: centre is given relative to the top-left corner; matrix maps output -> input
+    cx -= W * 0.5
+    cy -= H * 0.5
+    a = math.radians(-angle)
+    cos, sin = math.cos(a), math.sin(a)
+    # inverse affine matrix of torchvision's _get_inverse_affine_matrix (scale 1, no shear/translate)
+    m = [cos, sin, 0.0, -sin, cos, 0.0]
+    m[2] += m[0] * (-cx) + m[1] * (-cy) + cx
+    m[5] += m[3] * (-cx) + m[4] * (-cy) + cy
+    theta = torch.tensor(m, dtype=torch.float32).view(1, 2, 3)
+    # _gen_affine_grid: base grid in pixel units centred on the image, normalised by half sizes
+    xs = torch.linspace(-W * 0.5 + 0.5, W * 0.5 - 0.5, W)
+    ys = torch.linspace(-H * 0.5 + 0.5, H * 0.5 - 0.5, H)
+    base = torch.stack([xs[None, :].expand(H, W), ys[:, None].expand(H, W), torch.ones(H, W)], -1).view(1, H * W, 3)
+    scale = torch.tensor([0.5 * W, 0.5 * H])
+    grid = base.bmm(theta.transpose(1, 2) / scale).view(1, H, W, 2)
+    out = F.grid_sample(img[None].float(), grid, mode="nearest", padding_mode="zeros", align_corners=False)
+    return out[0].to(img.dtype)
+
+
+# ------------------------------------------------------------------------------------ install
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install():
+    if getattr(sys.modules.get("mmcv"), "_vidar_functional_stub", False):
+        return
+    ident = lambda *a, **k: (lambda f: f)
+    _mod("mmcv", _vidar_functional_stub=True, ConfigDict=ConfigDict, deprecated_api_warning=ident,
+         mkdir_or_exist=lambda p: Path(p).mkdir(parents=True, exist_ok=True))
+    _mod("mmcv.cnn", Linear=nn.Linear, xavier_init=xavier_init, constant_init=constant_init,
+         build_activation_layer=build_activation_layer, build_norm_layer=build_norm_layer,
+         bias_init_with_prob=lambda p: float(-math.log((1 - p) / p)))
+    _mod("mmcv.cnn.bricks")
+    _mod("mmcv.cnn.bricks.registry", ATTENTION=ATTENTION, FEEDFORWARD_NETWORK=FEEDFORWARD_NETWORK,
+         POSITIONAL_ENCODING=POSITIONAL_ENCODING, TRANSFORMER_LAYER=TRANSFORMER_LAYER,
+         TRANSFORMER_LAYER_SEQUENCE=TRANSFORMER_LAYER_SEQUENCE)
+    _mod("mmcv.cnn.bricks.transformer",
+         build_attention=lambda cfg, default_args=None: build_from_cfg(cfg, ATTENTION, default_args),
+         build_feedforward_network=lambda cfg, default_args=None: build_from_cfg(cfg, FEEDFORWARD_NETWORK, default_args),
+         build_positional_encoding=lambda cfg, default_args=None: build_from_cfg(cfg, POSITIONAL_ENCODING, default_args),
+         build_transformer_layer=lambda cfg, default_args=None: build_from_cfg(cfg, TRANSFORMER_LAYER, default_args),
+         build_transformer_layer_sequence=lambda cfg, default_args=None: build_from_cfg(cfg, TRANSFORMER_LAYER_SEQUENCE, default_args),
+         TransformerLayerSequence=TransformerLayerSequence, FFN=FFN)
+    _mod("mmcv.runner", force_fp32=ident, auto_fp16=ident, BaseModule=BaseModule)
+    _mod("mmcv.runner.base_module", BaseModule=BaseModule, ModuleList=ModuleList, Sequential=Sequential)
+    ext = types.SimpleNamespace(load_ext=lambda *a, **k: types.SimpleNamespace())
+    _mod("mmcv.utils", ConfigDict=ConfigDict, build_from_cfg=build_from_cfg, deprecated_api_warning=ident,
+         to_2tuple=lambda x: (x, x), TORCH_VERSION=torch.__version__,
+         digit_version=lambda v: tuple(int(x) for x in v.split("+")[0].split(".")[:3]), ext_loader=ext)
+    _mod("mmcv.ops")
+    _mod("mmcv.ops.multi_scale_deform_attn",
+         multi_scale_deformable_attn_pytorch=multi_scale_deformable_attn_pytorch)
+    _mod("mmdet")
+    _mod("mmdet.models", HEADS=HEADS, DETECTORS=DETECTORS, build_loss=lambda cfg: None)
+    _mod("mmdet.models.utils", build_transformer=lambda cfg, default_args=None: build_from_cfg(cfg, TRANSFORMER, default_args))
+    _mod("mmdet.models.utils.builder", TRANSFORMER=TRANSFORMER)
+    _mod("cv2")                                   # decoder.py imports it, uses it nowhere on this path
+    _mod("torchvision")
+    _mod("torchvision.transforms")
+    _mod("torchvision.transforms.functional", rotate=rotate)
+
+
+def reference_modules():
+    """Import the reference's bevformer/modules package files in place (package namespace
+    `refbev.modules`, so relative imports resolve against /root/reference without running the
+    plugin's top-level __init__, which drags in datasets / mmdet3d)."""
+    install()
+    if "refbev.modules" not in sys.modules:
+        pkg = _mod("refbev"); pkg.__path__ = []
+        mp = _mod("refbev.modules"); mp.__path__ = [str(PLUGIN / "bevformer/modules")]
+        for name in ("multi_scale_deformable_attn_function", "spatial_cross_attention",
+                     "temporal_self_attention", "custom_base_transformer_layer", "decoder", "encoder",
+                     "ray_operations", "transformer", "encoder_v2", "vidar_decoder", "vidar_transformer"):
+            importlib.import_module("refbev.modules." + name)
+        lr = sys.modules["refbev.modules.ray_operations.latent_rendering"]
+        d = list(lr.get_bev_grids.__defaults__)
+        d[d.index("cuda")] = "cpu"                     # hard-coded device default (latent_rendering.py:14)
+        lr.get_bev_grids.__defaults__ = tuple(d)
+    return sys.modules["refbev.modules"]

@@ -15,11 +15,13 @@ from .registry import FEEDFORWARD_NETWORK, POSITIONAL_ENCODING
 
 
 def xavier_init(module, gain=1, bias=0, distribution="normal"):
-    for m in ([module] if not isinstance(module, nn.Sequential) else module):
-        if hasattr(m, "weight") and m.weight is not None and m.weight.dim() > 1:
-            (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(m.weight, gain=gain)
-        if hasattr(m, "bias") and m.bias is not None:
-            nn.init.constant_(m.bias, bias)
+    """[3P] mmcv.cnn.xavier_init: acts on the module ITSELF only -- called on an nn.Sequential (the
+    reference does that for its can_bus_mlp, transformer.py:109, vidar_head_base.py) it is a no-op,
+    which leaves those Linear biases at PyTorch's default initialisation."""
+    if hasattr(module, "weight") and module.weight is not None:
+        (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(module.weight, gain=gain)
+    if hasattr(module, "bias") and module.bias is not None:
+        nn.init.constant_(module.bias, bias)
 
 
 def constant_init(module, val, bias=0):

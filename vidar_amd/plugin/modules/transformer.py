@@ -34,6 +34,9 @@ class PerceptionTransformer(nn.Module):
         self.two_stage_num_proposals = two_stage_num_proposals
         self.level_embeds = nn.Parameter(torch.Tensor(num_feature_levels, embed_dims))
         self.cams_embeds = nn.Parameter(torch.Tensor(num_cams, embed_dims))
+        # detection-branch leftover (transformer.py:73): unused on this path, kept so that released
+        # checkpoints load with strict=True; frozen so that DDP never waits for its gradient
+        self.reference_points = nn.Linear(embed_dims, 3).requires_grad_(False)
         self.can_bus_mlp = nn.Sequential(nn.Linear(18, embed_dims // 2), nn.ReLU(inplace=True),
                                          nn.Linear(embed_dims // 2, embed_dims), nn.ReLU(inplace=True))
         if can_bus_norm:
@@ -50,6 +53,7 @@ class PerceptionTransformer(nn.Module):
                 m.init_weights()
         nn.init.normal_(self.level_embeds)
         nn.init.normal_(self.cams_embeds)
+        xavier_init(self.reference_points, distribution="uniform", bias=0.)
         xavier_init(self.can_bus_mlp, distribution="uniform", bias=0.)
 
     def get_bev_features(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length=[0.512, 0.512],
