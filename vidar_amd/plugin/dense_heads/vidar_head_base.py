@@ -201,11 +201,16 @@ class ViDARHeadBase(ViDARHeadTemplate):
                     o = origin_grids[b, f].view(1, 3)
                     p = pts[f * per_frame:(f + 1) * per_frame]
                     r = p - o
-                    pred = (r / torch.sqrt((r ** 2).sum(1, keepdim=True))
-                            * dist[f * per_frame:(f + 1) * per_frame].view(-1, 1)) * 0.1
+                    d = dist[f * per_frame:(f + 1) * per_frame]
+                    # get_rendered_pcds keeps rays with a positive rendered distance only (:392-395);
+                    # a dense voxel centre that coincides with the origin (zero-length ray) drops out
+                    live = d > 0
+                    unit = r / torch.sqrt((r ** 2).sum(1, keepdim=True))
+                    pred = torch.where(live[:, None], unit * d.view(-1, 1), torch.zeros_like(r)) * 0.1
                     gt = (gt_grids[b] - o) * 0.1
                     valid = inside & (tindex[b] == f)
-                    ls, lt, _, _ = chamfer_distance(pred[None], gt[None], dst_valid=valid[None])
+                    ls, lt, _, _ = chamfer_distance(pred[None], gt[None], dst_valid=valid[None],
+                                                    src_valid=live[None])
                     has = (valid.sum() > 0).to(ls.dtype)
                     total = total + (ls + lt) / 2. * lw[f] * has
             loss_dict["loss.dense_voxel"] = total / (float(np.sum(loss_weight)) * bs) * self.dense_loss_weight

@@ -11,41 +11,50 @@ from ..third_lib.chamferdist import knn_points
 FAR = 1.0e6   # parking coordinate for masked-out target points
 
 
+def _valid_first(x, valid):
+    """stable partition along dim 1: valid points first, the rest parked at FAR.
+    -> (points, valid mask in the new order, device-side count)"""
+    order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)
+    x = torch.gather(torch.nan_to_num(x), 1, order.unsqueeze(-1).expand(-1, -1, x.shape[-1]))
+    valid = torch.gather(valid, 1, order)
+    return torch.where(valid.unsqueeze(-1), x, x.new_full((), FAR)), valid, valid.sum(1).to(torch.int64)
+
+
+def _reduce(loss, valid, reduction):
+    if valid is not None:
+        loss = loss * valid.to(loss.dtype)
+    if reduction == "sum":
+        return loss.sum()
+    if reduction == "mean":
+        if valid is None:
+            return loss.mean()
+        return loss.sum() / valid.sum().clamp(min=1).to(loss.dtype)
+    if reduction != "none":
+        raise NotImplementedError(reduction)
+    return loss
+
+
 def chamfer_distance(src, dst, src_weight=1.0, dst_weight=1.0, criterion_mode="l2", reduction="mean",
-                     dst_valid=None):
+                     dst_valid=None, src_valid=None):
     """src [B,N,3], dst [B,M,3] -> (loss_src, loss_dst, indices1 [B,N], indices2 [B,M]).
     criterion 'l2' only (sum of squared differences), reductions 'mean' | 'sum' | 'none'.
 
-    Extension (not in mmdet3d): `dst_valid` [B,M] bool keeps the tensor shapes static -- invalid
-    target points are ignored exactly as if they had been removed before the call (no host sync):
-    they can never be a nearest neighbour and 'mean' divides by the number of valid points.
-    With `dst_valid` the returned indices refer to the valid-first permutation of `dst`."""
+    Extension (not in mmdet3d): `dst_valid` [B,M] / `src_valid` [B,N] bool keep the tensor shapes
+    static -- invalid points are ignored exactly as if they had been removed before the call (no
+    host sync): they can never be a nearest neighbour, contribute no loss, and 'mean' divides by
+    the number of valid points.  With a mask the returned indices refer to the valid-first
+    permutation of that cloud."""
     if criterion_mode != "l2":
         raise NotImplementedError("only criterion_mode='l2' is on ViDAR's path")
-    lengths = None
+    # stable partition: valid points first, their count stays on the device as `lengths`
+    # (the KNN kernels read lengths on device and skip everything beyond them)
+    len_src = len_dst = None
+    if src_valid is not None:
+        src, src_valid, len_src = _valid_first(src, src_valid)
     if dst_valid is not None:
-        # stable partition: valid points first, their count stays on the device as `lengths`
-        # (the KNN kernels read lengths on device and skip everything beyond them)
-        order = torch.argsort((~dst_valid).to(torch.int8), dim=1, stable=True)
-        dst = torch.gather(torch.nan_to_num(dst), 1, order.unsqueeze(-1).expand(-1, -1, dst.shape[-1]))
-        dst_valid = torch.gather(dst_valid, 1, order)
-        lengths = dst_valid.sum(1).to(torch.int64)
-        dst = torch.where(dst_valid.unsqueeze(-1), dst, dst.new_full((), FAR))
-    fwd = knn_points(src, dst, lengths2=lengths)
-    bwd = knn_points(dst, src, lengths1=lengths)
-    loss_src = fwd.dists[..., 0] * src_weight
-    loss_dst = bwd.dists[..., 0] * dst_weight
-    if dst_valid is not None:
-        loss_dst = loss_dst * dst_valid.to(loss_dst.dtype)
-    if reduction == "sum":
-        loss_src, loss_dst = loss_src.sum(), loss_dst.sum()
-    elif reduction == "mean":
-        loss_src = loss_src.mean()
-        if dst_valid is None:
-            loss_dst = loss_dst.mean()
-        else:
-            n = dst_valid.sum()
-            loss_dst = loss_dst.sum() / n.clamp(min=1).to(loss_dst.dtype)
-    elif reduction != "none":
-        raise NotImplementedError(reduction)
+        dst, dst_valid, len_dst = _valid_first(dst, dst_valid)
+    fwd = knn_points(src, dst, lengths1=len_src, lengths2=len_dst)
+    bwd = knn_points(dst, src, lengths1=len_dst, lengths2=len_src)
+    loss_src = _reduce(fwd.dists[..., 0] * src_weight, src_valid, reduction)
+    loss_dst = _reduce(bwd.dists[..., 0] * dst_weight, dst_valid, reduction)
     return loss_src, loss_dst, fwd.idx[..., 0], bwd.idx[..., 0]
