@@ -33,6 +33,9 @@ class ViDARBEVFormerHead(nn.Module):
 
     def init_weights(self):
         self.transformer.init_weights()
+        if hasattr(self.transformer, "reference_points"):
+            del self.transformer.reference_points      # vidar_bevformer_head.py:20-23: released
+            # checkpoints therefore carry no pts_bbox_head.transformer.reference_points.* keys
 
     def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, return_intermediate=False):
         assert only_bev
