@@ -85,12 +85,15 @@ def zero_dropout(m):
 
 
 def build_reference():
-    head_mod, e2e = R.reference_heads()
+    head_mod, _ = R.reference_heads()
+    e2e, eval_utils = R.reference_eval_stack()
     ident = lambda *a, **k: (lambda f: f)
-    ns = dict(torch=torch, np=np, copy=copy, e2e_predictor_utils=e2e, auto_fp16=ident, force_fp32=ident)
+    import os
+    ns = dict(torch=torch, np=np, copy=copy, os=os, mmcv=sys.modules["mmcv"], e2e_predictor_utils=e2e,
+              eval_utils=eval_utils, auto_fp16=ident, force_fp32=ident)
     src = (R.PLUGIN / "bevformer/detectors/vidar.py").read_text()
     a = src.index("    def _get_history_ref_to_previous_transform(")
-    b = src.index("    def forward_test(self, img_metas, img=None,")
+    b = src.index("    def _viz_pcd(self, pred_pcd, pred_ctr,  output_path, gt_pcd=None):")
     bsrc = (R.PLUGIN / "bevformer/detectors/bevformer.py").read_text()
     c = bsrc.index("    def _obtain_frozen_history_bev(")
     d = bsrc.index("    @auto_fp16(apply_to=('img', 'points'))\n    def forward_train(")
@@ -123,6 +126,8 @@ def build_reference():
     det.random_drop_prev_start_idx, det.random_drop_prev_end_idx = 1, None
     det.grid_mask_prev = False
     det.backwarded_prev_frame_num = 1
+    det.test_future_frame_num = FUTURE
+    det._viz_pcd_flag = det._submission = False
     proj = projections()
 
     def extract_feat(img, img_metas=None, len_queue=None):
@@ -170,16 +175,24 @@ def main():
     params = dict(det.named_parameters())
     grads = torch.autograd.grad(total, [params[n] for n in names])
 
+    # ---- forward_test with the same weights (vidar.py:389-502) -------------------------------------
+    with torch.no_grad():
+        res = det.forward_test([copy.deepcopy(metas)], img=img.clone(), gt_points=[torch.from_numpy(gt)])[0]
+    det.train()
+    test_keys = sorted(res)
+    test_vals = np.array([[res[k]["count"], res[k]["chamfer_distance"], res[k]["l1_error"], res[k]["absrel_error"]]
+                          for k in test_keys], np.float64)
+
     sd = {"sd/" + k: v.detach().numpy() for k, v in det.state_dict().items()}
     np.savez_compressed(
-        HERE / "detector_small.npz", **sd, cfg_json=np.array(json.dumps(model_cfg())),
+        HERE / "detector_small.npz", **sd, test_keys=np.array(test_keys), test_values=test_vals, cfg_json=np.array(json.dumps(model_cfg())),
         loss_names=np.array(sorted(losses)), loss_values=np.array([float(losses[k]) for k in sorted(losses)]),
         noise_seeds=np.array([50 + i for i in range(len(NOISE))]),
         noise_shapes=np.array([list(n.shape) for n in NOISE]),
         noise_sums=np.array([float(n.double().sum()) for n in NOISE]),
         grad_names=np.array(names), **{f"grad{i}": g.numpy() for i, g in enumerate(grads)})
     print("wrote detector_small.npz", {k: round(float(v), 5) for k, v in losses.items()},
-          [tuple(n.shape) for n in NOISE], "keys", len(sd))
+          [tuple(n.shape) for n in NOISE], "keys", len(sd), "test", dict(zip(test_keys, test_vals.round(4).tolist())))
 
 
 if __name__ == "__main__":

@@ -12,6 +12,7 @@ torchvision's `rotate`.  None of the reference's own arithmetic lives here.
 Used only by the golden generators; never imported by the product or by the tests."""
 import copy
 import importlib
+import importlib.util
 import math
 import sys
 import types
@@ -336,3 +337,30 @@ def reference_detector_helpers():
     ns = dict(torch=torch, np=np, e2e_predictor_utils=e2e)
     exec("class Helpers:\n" + src[start:end], ns)
     return ns["Helpers"]
+
+
+def reference_eval_stack():
+    """For forward_test: the reference's chamferdist python package (third_lib/chamfer_dist/...) on top
+    of its own ext.cpp + knn_cpu.cpp compiled for the host (oracle/_ref/ref_chamferdist_C.so), and
+    its utils/eval_utils.py.  -> (e2e_predictor_utils, eval_utils) with working chamfer_distance."""
+    _, e2e = reference_heads()
+    if not hasattr(sys.modules.get("chamferdist"), "_vidar_real"):
+        sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+        from oracle import build_ref
+        if not build_ref.so_path("ref_chamferdist_C").exists():
+            build_ref.build(verbose=False)
+        pkg = _mod("chamferdist", _vidar_real=True)
+        pkg.__path__ = []
+        pkg._C = build_ref.load("ref_chamferdist_C")
+        sys.modules["chamferdist._C"] = pkg._C
+        spec = importlib.util.spec_from_file_location(
+            "chamferdist.chamfer", REF / "third_lib/chamfer_dist/chamferdist/chamferdist/chamfer.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules["chamferdist.chamfer"] = m
+        spec.loader.exec_module(m)
+        pkg.ChamferDistance = m.ChamferDistance
+        e2e.ChamferDistance = m.ChamferDistance
+        e2e.chamfer_distance = m.ChamferDistance()         # module-level instance (e2e_predictor_utils.py:163)
+    if "refbev.utils.eval_utils" not in sys.modules:
+        importlib.import_module("refbev.utils.eval_utils")
+    return e2e, sys.modules["refbev.utils.eval_utils"]

@@ -27,11 +27,9 @@ def _pyramids(img):
             for s, p in zip(SHAPES, proj)]
 
 
-def test_forward_train_matches_reference_orchestration():
-    from oracle import cpu_ops
+def _model_and_sample(gold):
     from vidar_amd.plugin.registry import build_detector
     from vidar_amd.synthetic import make_sample
-    gold = np.load(GOLD, allow_pickle=False)
     cfg = json.loads(str(gold["cfg_json"]))
     torch.manual_seed(0); np.random.seed(0)
     model = build_detector(cfg)
@@ -46,10 +44,32 @@ def test_forward_train_matches_reference_orchestration():
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    model.train()
-
     metas, gt = make_sample(4, queue_length=2, future_frames=3, rays_per_frame=50, num_cams=2)
     img = torch.randn(1, 3, 2, 3, 24, 40, generator=torch.Generator().manual_seed(8))
+    return model, metas, gt, img
+
+
+def test_forward_test_matches_reference_orchestration():
+    """history BEV -> auto-regressive futures -> arg-max decode -> CD / L1 / AbsRel per frame
+    (vidar.py:389-502, with the reference's own chamferdist + knn_cpu.cpp build and eval_utils)."""
+    from oracle import cpu_ops
+    gold = np.load(GOLD, allow_pickle=False)
+    model, metas, gt, img = _model_and_sample(gold)
+    with cpu_ops.patched(), torch.no_grad():
+        res = model(return_loss=False, img_metas=[copy.deepcopy(metas)], gt_points=[torch.from_numpy(gt)],
+                    img_feats=_pyramids(img))[0]
+    assert sorted(res) == [str(k) for k in gold["test_keys"]]
+    for k, want in zip(gold["test_keys"], gold["test_values"]):
+        r = res[str(k)]
+        got = [r["count"], r["chamfer_distance"], r["l1_error"], r["absrel_error"]]
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5, err_msg=str(k))
+
+
+def test_forward_train_matches_reference_orchestration():
+    from oracle import cpu_ops
+    gold = np.load(GOLD, allow_pickle=False)
+    model, metas, gt, img = _model_and_sample(gold)
+    model.train()
     noise = []
     for seed, shape, total in zip(gold["noise_seeds"], gold["noise_shapes"], gold["noise_sums"]):
         n = -torch.empty(*[int(v) for v in shape]).exponential_(generator=torch.Generator().manual_seed(int(seed))).log()
