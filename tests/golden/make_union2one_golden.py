@@ -42,6 +42,33 @@ def transform_matrix(translation=np.array([0, 0, 0]), rotation=Quaternion([1, 0,
     return tm
 
 
+def quaternion_yaw(q):                  # [3P] nuscenes.eval.common.utils
+    v = np.dot(q.rotation_matrix, np.array([1, 0, 0]))
+    return np.arctan2(v[1], v[0])
+
+
+def _quat_array(self, dtype=None, copy=None):
+    return np.asarray(self.q, dtype)
+Quaternion.__array__ = _quat_array      # pyquaternion converts to (w, x, y, z) when assigned into an array
+Quaternion.__len__ = lambda self: 4
+Quaternion.__getitem__ = lambda self, i: self.q[i]
+
+
+def info_record(seed):
+    rng = np.random.default_rng(seed)
+    def quat():
+        q = rng.normal(size=4); return (q / np.linalg.norm(q)).tolist()
+    cams = {}
+    for c in ("CAM_FRONT", "CAM_BACK"):
+        a = rng.normal(size=(3, 3)); r, _ = np.linalg.qr(a)
+        cams[c] = dict(data_path=f"{c}.jpg", sensor2lidar_rotation=r, sensor2lidar_translation=rng.normal(size=3),
+                       cam_intrinsic=np.array([[1266.4, 0, 816.2], [0, 1266.4, 491.5], [0, 0, 1]]))
+    return dict(token=f"tok{seed}", lidar_path="x.bin", sweeps=[], ego2global_translation=rng.normal(size=3).tolist(),
+                ego2global_rotation=quat(), lidar2ego_translation=[0.94, 0.0, 1.84], lidar2ego_rotation=quat(),
+                prev="p", next="n", scene_token="sc", can_bus=rng.normal(size=18), frame_idx=3,
+                timestamp=1533151603547590, cams=cams)
+
+
 class DC:                               # [3P] mmcv.parallel.DataContainer, as far as union2one uses it
     def __init__(self, data, cpu_only=False, stack=False):
         self.data = data
@@ -123,8 +150,22 @@ def main():
             for index in (0, 5, 12, 19):
                 for ri in (1, 2, -1):
                     lists[(q, f, index, ri)] = ns["lists"](o, index, ri)
+    # get_data_info (nuscenes_dataset.py:153-227) + the template's extra fields
+    dsrc = (REF / "nuscenes_dataset.py").read_text()
+    a = dsrc.index("        info = self.data_infos[index]\n        # standard protocal modified from SECOND.Pytorch")
+    b = dsrc.index("        return input_dict\n\n    def __getitem__(self, idx):")
+    ns["quaternion_yaw"] = quaternion_yaw
+    exec("def get_data_info(self, index):\n" + dsrc[a:b] + "        return input_dict\n", ns)
+    infos_out = {}
+    for seed in (0, 1, 2):
+        o = type("O", (), {})()
+        o.data_infos, o.modality, o.test_mode, o.include_test = [info_record(seed)], dict(use_camera=True), True, False
+        d = ns["get_data_info"](o, 0)
+        d.update(lidar2ego_translation=o.data_infos[0]["lidar2ego_translation"],
+                 lidar2ego_rotation=o.data_infos[0]["lidar2ego_rotation"], cam2img=d["cam_intrinsic"])
+        infos_out[seed] = d
     with open(HERE / "union2one.pkl", "wb") as fh:
-        pickle.dump(dict(cases=cases, scenes="AAAAAABBBBCCCCCCCCDD", scans=scans, lists=lists), fh, protocol=4)
+        pickle.dump(dict(infos=infos_out, cases=cases, scenes="AAAAAABBBBCCCCCCCCDD", scans=scans, lists=lists), fh, protocol=4)
     print("wrote union2one.pkl", {k: (None if v["ret"] is None else v["ret"]["gt_points"].shape) for k, v in cases.items()},
           len(scans), len(lists))
 

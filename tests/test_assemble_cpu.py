@@ -77,3 +77,18 @@ def test_assembled_sample_drives_the_model(gold):
     # frame 3 (the reference frame) maps onto itself
     np.testing.assert_allclose(last["total_cur2ref_lidar_transform"][3], np.eye(4), atol=1e-9)
     assert [m["prev_bev_exists"] for m in s["img_metas"].values()] == [False, True, True, True]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_frame_meta_from_info_matches_reference(gold, seed):
+    from make_union2one_golden import info_record
+    from vidar_amd.data import frame_meta_from_info
+    got = frame_meta_from_info(info_record(seed))
+    want = gold["infos"][seed]
+    assert sorted(got) == sorted(want)
+    for k, w in want.items():
+        if isinstance(w, (list, np.ndarray)) and len(w) and not isinstance(w[0], str):
+            np.testing.assert_allclose(np.asarray(got[k], np.float64), np.asarray(w, np.float64), rtol=1e-12, atol=1e-12,
+                                       err_msg=k)
+        else:
+            assert got[k] == w, k

@@ -43,6 +43,49 @@ def transform_matrix(translation, rotation, inverse: bool = False) -> np.ndarray
     return tm
 
 
+def frame_meta_from_info(info: dict) -> dict:
+    """nuScenes-style info dict (mmdet3d `nuscenes_infos_temporal_*.pkl` entry) -> the per-frame meta
+    the model and union2one read: lidar2img per camera, lidar2global_rotation, can_bus with the
+    pose patched in (CustomNuScenesDataset.get_data_info, datasets/nuscenes_dataset.py:153-227, plus
+    the lidar2ego / cam2img fields of the template's override, nuscenes_vidar_dataset_template.py:70-80)."""
+    lidar2ego_r = _rotation_matrix(info["lidar2ego_rotation"])
+    ego2global_r = _rotation_matrix(info["ego2global_rotation"])
+    meta = dict(sample_idx=info["token"], pts_filename=info["lidar_path"], sweeps=info["sweeps"],
+                ego2global_translation=info["ego2global_translation"],
+                ego2global_rotation=info["ego2global_rotation"],
+                lidar2global_rotation=ego2global_r @ lidar2ego_r, prev_idx=info["prev"], next_idx=info["next"],
+                scene_token=info["scene_token"], can_bus=info["can_bus"], frame_idx=info["frame_idx"],
+                timestamp=info["timestamp"] / 1e6, lidar2ego_translation=info["lidar2ego_translation"],
+                lidar2ego_rotation=info["lidar2ego_rotation"])
+    paths, lidar2img, intrinsics, lidar2cam = [], [], [], []
+    for cam in info["cams"].values():
+        paths.append(cam["data_path"])
+        r = np.linalg.inv(cam["sensor2lidar_rotation"])
+        t = cam["sensor2lidar_translation"] @ r.T
+        rt = np.eye(4)
+        rt[:3, :3] = r.T
+        rt[3, :3] = -t
+        k = cam["cam_intrinsic"]
+        viewpad = np.eye(4)
+        viewpad[:k.shape[0], :k.shape[1]] = k
+        lidar2img.append(viewpad @ rt.T)
+        intrinsics.append(viewpad)
+        lidar2cam.append(rt.T)
+    meta.update(img_filename=paths, lidar2img=lidar2img, cam_intrinsic=intrinsics, lidar2cam=lidar2cam,
+                cam2img=intrinsics)
+    # overwrite the can-bus pose with the ego pose; yaw in [0, 360) degrees / radians
+    can_bus = meta["can_bus"]
+    can_bus[:3] = info["ego2global_translation"]
+    can_bus[3:7] = info["ego2global_rotation"]
+    v = ego2global_r @ np.array([1.0, 0.0, 0.0])
+    angle = np.arctan2(v[1], v[0]) / np.pi * 180          # [3P] nuscenes quaternion_yaw
+    if angle < 0:
+        angle += 360
+    can_bus[-2] = angle / 180 * np.pi
+    can_bus[-1] = angle
+    return meta
+
+
 def usable_indices(data_infos: Sequence[dict], future_length: int, queue_length: int, test_mode: bool,
                    load_frame_interval: Optional[int] = None) -> List[int]:
     """Frames with enough history (test mode only: the 4d-occ protocol) and `future_length` future
