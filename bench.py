@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="vidar_1_8_nusc_1future")
     ap.add_argument("--rays-per-frame", type=int, default=30000)
+    ap.add_argument("--samples-per-gpu", type=int, default=1,
+                    help="per-GPU batch (the reference is fixed at 1, vidar.py:306; BASELINE config 3 sizes it to HBM)")
     ap.add_argument("--no-backbone", action="store_true",
                     help="feed FPN pyramids instead of images (hot path of SURVEY 8a only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,16 +139,17 @@ def main():
     model = T.build_model(cfg).to(dev).train()
     ddp = T.wrap_ddp(model, local)
     opt = T.build_optimizer(model)
-    metas, gt = make_sample(seed=100 + rank, queue_length=cfg["queue_length"],
-                            future_frames=cfg["future_frames"], rays_per_frame=args.rays_per_frame,
-                            num_cams=cfg["num_cams"], img_hw=cfg["img_hw"])
+    spg = args.samples_per_gpu
+    samples = [make_sample(seed=100 + rank * spg + i, queue_length=cfg["queue_length"],
+                           future_frames=cfg["future_frames"], rays_per_frame=args.rays_per_frame,
+                           num_cams=cfg["num_cams"], img_hw=cfg["img_hw"]) for i in range(spg)]
+    batch = dict(img_metas=[m for m, _ in samples], gt_points=[torch.from_numpy(g).to(dev) for _, g in samples])
     if args.no_backbone:
-        feats = fpn_features(200 + rank, cfg["queue_length"] + 1, num_cams=cfg["num_cams"],
-                             shapes=cfg["fpn_shapes"], device=dev)
-        batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)], img_feats=feats)
+        batch["img_feats"] = fpn_features(200 + rank, cfg["queue_length"] + 1, num_cams=cfg["num_cams"],
+                                          shapes=cfg["fpn_shapes"], device=dev, bs=spg)
     else:
-        imgs = synthetic_images(200 + rank, cfg["queue_length"] + 1, cfg["num_cams"], cfg["img_hw"], dev)
-        batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt).to(dev)], img=imgs)
+        batch["img"] = torch.cat([synthetic_images(200 + rank * spg + i, cfg["queue_length"] + 1,
+                                                   cfg["num_cams"], cfg["img_hw"], dev) for i in range(spg)])
 
     grouped = dist.is_available() and dist.is_initialized()
 
@@ -185,7 +188,7 @@ def main():
         achieved = dom["bytes_per_call"] / (dom["avg_ms"] * 1e-3) / 1e9
         hip_ms = sum(v["total_ms"] for v in ops.values()) / args.steps
         out = {
-            "metric": "train samples/sec (6-cam->BEV step)", "value": world * args.steps / elapsed,
+            "metric": "train samples/sec (6-cam->BEV step)", "value": world * spg * args.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -194,7 +197,7 @@ def main():
                                     else f"{args.config} (no image backbone): FPN pyramids -> ")
                                    + "5x BEV encode (6 layers TSA+SCA, LatentRendering, bev 200x200) -> head -> "
                                      "ray CE + gumbel render + chamfer -> backward -> clip -> AdamW",
-                       "global_batch": world, "rays_per_frame": args.rays_per_frame,
+                       "global_batch": world * spg, "rays_per_frame": args.rays_per_frame,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,

@@ -111,3 +111,43 @@ def test_without_oracle_patch_the_step_refuses_to_run_on_cpu():
     model = T.build_model(cfg).train()
     with pytest.raises(RuntimeError):
         model(return_loss=True, **batch)
+
+
+@pytest.mark.parametrize("name", ["vidar_1_8_nusc_1future", "vidar_1_8_nusc_3future"])
+def test_batch_of_two_equals_two_single_samples(name):
+    """Per-GPU batches above 1 (BASELINE config 3; the reference asserts bs == 1, vidar.py:306, and its
+    encoder re-stacks `prev_bev[:bs]`, encoder.py:244-245, which mixes samples for bs > 1): every
+    sample of a batch must see exactly what it sees alone.  The dense-voxel loss is a mean over
+    samples; the CE term is weighted by each sample's number of valid rays."""
+    import copy
+    from oracle import cpu_ops
+    from vidar_amd import train as T
+    from vidar_amd.synthetic import fpn_features, make_sample
+    torch.manual_seed(0); np.random.seed(0)
+    cfg = get_config(name, bev_h=24, bev_w=24)
+    model = T.build_model(cfg).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "random_drop_prev_rate"):
+            m.random_drop_prev_rate = 0.0
+    ms, gts = [], []
+    for s in (0, 1):
+        m, g = make_sample(s, rays_per_frame=100, future_frames=cfg["future_frames"])
+        ms.append(m); gts.append(torch.from_numpy(g))
+    feats = fpn_features(0, 5, shapes=[(15, 25), (8, 13), (4, 7), (2, 4)], bs=2)
+    noise = -torch.empty(6000, 512).exponential_(generator=torch.Generator().manual_seed(3)).log()
+    model.future_pred_head.gumbel_noise_fn = lambda R, K: noise[:R]
+    with cpu_ops.patched(), torch.no_grad():
+        both = model(return_loss=True, img_metas=copy.deepcopy(ms), gt_points=gts, img_feats=feats)
+        single = [model(return_loss=True, img_metas=[copy.deepcopy(ms[b])], gt_points=[gts[b]],
+                        img_feats=[f[b:b + 1] for f in feats]) for b in (0, 1)]
+    for k, v in both.items():
+        mean = (float(single[0][k]) + float(single[1][k])) / 2
+        tol = 1e-5 if "dense_voxel" in k else 5e-3
+        assert abs(float(v) - mean) <= tol * abs(mean), (k, float(v), mean)
+    # a batch whose samples disagree on the history flags has no defined reading
+    bad = copy.deepcopy(ms)
+    bad[1][2]["prev_bev_exists"] = not bad[1][2]["prev_bev_exists"]
+    with cpu_ops.patched(), torch.no_grad(), pytest.raises(ValueError):
+        model(return_loss=True, img_metas=bad, gt_points=gts, img_feats=feats)

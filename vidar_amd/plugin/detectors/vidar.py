@@ -169,7 +169,13 @@ class ViDAR(nn.Module):
                                                         num_frames, grad=True)]
         if not cur_metas[0]["prev_bev_exists"]:
             prev_bev = None
-        assert len(prev_img_metas) == 1, "Only supports bs=1 for now."      # vidar.py:306
+        # The reference asserts bs == 1 here (vidar.py:306): it reads the history flags of sample 0
+        # for the whole batch.  Larger per-GPU batches are allowed when that reading is unambiguous,
+        # i.e. every sample of the batch has the same prev_bev_exists pattern.
+        flags = [[bool(meta[k]["prev_bev_exists"]) for k in range(len(meta))] for meta in prev_img_metas]
+        if any(f != flags[0] for f in flags[1:]):
+            raise ValueError("samples of one batch must share their prev_bev_exists pattern "
+                             "(the reference only supports bs=1, vidar.py:306)")
         exists = []
         for meta in prev_img_metas:
             ok = True

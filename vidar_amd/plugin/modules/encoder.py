@@ -109,7 +109,10 @@ class BEVFormerEncoder(TransformerLayerSequence):
             bev_query = output
             if self.latent_rendering_lid is not None:
                 if prev_bev is not None and lid in self.latent_rendering_lid:
-                    prev_bev = torch.stack([prev_bev[:bs], bev_query], 1).reshape(bs * 2, len_bev, -1)
+                    # reference: prev_bev[:bs] (encoder.py:244-245) -- the history rows only for bs == 1,
+                    # the layout is (b0 prev, b0 cur, b1 prev, ...): take every sample's history row
+                    hist = prev_bev.view(bs, 2, len_bev, -1)[:, 0]
+                    prev_bev = torch.stack([hist, bev_query], 1).reshape(bs * 2, len_bev, -1)
             if self.return_intermediate:
                 intermediate.append(output)
         if self.return_intermediate:
