@@ -137,6 +137,11 @@ int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
  * ------------------------------------------------------------------------- */
 /* tuning/A-B switch: 1 (default) = XCD-banded workgroup order, 0 = plain blockIdx order */
 int vidar_msda_set_xcd_remap(int enabled);
+/* tuning/A-B switch of the backward scatter: 1 = the two half-waves of a wave own the same head of two
+ * adjacent queries and write the corner lines they share once (fewer atomic requests), 0 (default) =
+ * one (query, head) item per half-wave, every corner line written.  Results differ only in fp32
+ * summation order.  Returns the previous value. */
+int vidar_msda_set_bwd_pair_merge(int enabled);
 int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq,

@@ -99,6 +99,41 @@ def bench_msda_ab(which):
     lib().vidar_msda_set_xcd_remap(1)
 
 
+def bench_msda_pair(which):
+    """A/B of the pair-merging backward scatter (vidar_msda_set_bwd_pair_merge) on spatially coherent
+    queries (what the model produces: neighbouring BEV queries sample next to each other; the random
+    reference points of `bench_msda` share no lines) + agreement of both kernels."""
+    from oracle import msda as M   # operand generator only (bench tool, not product)
+    from vidar_amd._lib import lib
+    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_backward
+    fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
+    for name, B, shapes, Nq, P, px in (("TSA-like", 2, [(200, 200)], 40000, 4, 1.0),
+                                       ("SCA-like far (2 level-0 px between queries)", 6, fpn, 10000, 8, 2.0),
+                                       ("SCA-like near (8 px)", 6, fpn, 10000, 8, 8.0)):
+        value, sh, loc, w = M.make_case(0, B, shapes, Nq, P=P)
+        L = len(shapes)
+        side = int(Nq ** 0.5)
+        q = torch.arange(Nq)
+        step = px / shapes[0][1]                                   # in normalised image units
+        base = torch.stack([(q % side) * step + 0.1, (q // side) * step * 0.5 + 0.1], -1)   # [Nq, 2]
+        g = torch.Generator().manual_seed(1)
+        off = (torch.rand(1, 1, 8, L, P, 2, generator=g) - 0.5) * 0.02      # per (head, level, point), shared by queries
+        loc = (base[None, :, None, None, None, :] + off).expand(B, Nq, 8, L, P, 2).contiguous().clamp(0.0, 0.999)
+        value, sh, loc, w = value.cuda(), sh.cuda(), loc.cuda(), w.cuda()
+        lsi = M.level_start_index(shapes).cuda()
+        go = torch.randn(B, Nq, 256, device="cuda")
+        outs = {}
+        for flag in (0, 1):
+            lib().vidar_msda_set_bwd_pair_merge(flag)
+            outs[flag] = _msda_backward(value, sh, lsi, loc, w, go)
+            ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go))
+            report(f"msda_bwd {name} pair_merge={flag}", ms)
+        lib().vidar_msda_set_bwd_pair_merge(0)
+        for a, b, nm in zip(outs[0], outs[1], ("grad_value", "grad_loc", "grad_w")):
+            print(json.dumps({"agreement": nm, "max_abs_diff": float((a - b).abs().max()),
+                              "scale": float(a.abs().max())}), flush=True)
+
+
 def bench_msda(which):
     from oracle import msda as M   # operand generator only (bench tool, not product)
     from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_forward, _msda_backward

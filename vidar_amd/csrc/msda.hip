@@ -202,6 +202,133 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
   for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) grad_w[item0 * LP + i] = s_w[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, pair-merging variant (A/B switch vidar_msda_set_bwd_pair_merge, default off until it has
+// been measured).  The scatter sits on the atomic-unit wall (one request per instruction x 128-byte
+// line), so the only lever is fewer requests.  Here the two half-waves of a wave own the SAME head of
+// two ADJACENT queries (bq, bq+1): neighbouring BEV queries project next to each other, and on the
+// coarse pyramid levels / for far queries the same (level, point) sample of both lands in the same
+// pixel cell or in cells that share an edge.  The half-waves exchange their four corner line ids and
+// values by shuffle; a line both of them touch is written once, by the lower half, with the sum.
+// Results differ from the plain kernel only in fp32 summation order.
+// Workgroup = 4 waves = 4 heads x 2 queries; grid = ceil(B*Nq/2) query pairs x ceil(H/4) head groups.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPHeads = kThreads / 64;         // heads per workgroup (one wave each)
+constexpr int kPItems = 2 * kPHeads;           // LDS slots: [half][head]
+
+__global__ __launch_bounds__(kThreads) void msda_bwd_pair_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
+    const float* __restrict__ grad_out, float* __restrict__ grad_value,
+    float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv, int H, int Nq, int L, int P,
+    int64_t n_bq, int n_hg, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LP = L * P;
+  float* s_loc = smem;                         // [kPItems][LP*2]  in: loc, out: grad_loc
+  float* s_w = smem + kPItems * LP * 2;        // [kPItems][LP]    in: w,   out: grad_w
+  const int blk = xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;
+  const int64_t pair = blk / n_hg;
+  const int h0 = (blk % n_hg) * kPHeads;       // first head of this workgroup
+  const int nh = min(kPHeads, H - h0);         // valid heads here
+  const int64_t bq0 = pair * 2;
+  const int nhalf = (bq0 + 1 < n_bq) ? 2 : 1;  // valid queries here
+  // staging: per half one contiguous run of nh items (heads h0 .. h0+nh-1 of query bq0+half)
+  for (int half = 0; half < nhalf; ++half) {
+    const int64_t item_first = (bq0 + half) * H + h0;
+    float* dl = s_loc + half * kPHeads * LP * 2;
+    float* dw = s_w + half * kPHeads * LP;
+    for (int i = threadIdx.x; i < nh * LP * 2; i += kThreads) dl[i] = loc[item_first * LP * 2 + i];
+    for (int i = threadIdx.x; i < nh * LP; i += kThreads) dw[i] = attw[item_first * LP + i];
+  }
+  __syncthreads();
+  const int wv = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int half = lane / kBLanes, ch = lane % kBLanes;
+  if (wv < nh) {                                // wave-uniform: both halves take part in the shuffles
+    const bool live = half < nhalf;
+    const int64_t bq = bq0 + (live ? half : 0);
+    const int h = h0 + wv;
+    const int b = (int)(bq / Nq);
+    const int row_stride = H * kCh;
+    const int64_t item = bq * H + h;
+    const int64_t gbase = (int64_t)b * Nv * row_stride + h * kCh;   // element offset of channel 0
+    const float* vb = value + gbase + ch;
+    float* gvb = grad_value + ch;               // + global line offset below
+    const float go = live ? grad_out[item * kCh + ch] : 0.f;
+    const int slot = half * kPHeads + wv;
+    float* ml = s_loc + slot * LP * 2;
+    float* mw = s_w + slot * LP;
+    for (int l = 0; l < L; ++l) {
+      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+      const int64_t base = lsi[l] * row_stride;
+      for (int p = 0; p < P; ++p) {
+        float x = 0.f, y = 0.f, w = 0.f;
+        if (live) {
+          x = ml[(l * P + p) * 2] * Wl - 0.5f;
+          y = ml[(l * P + p) * 2 + 1] * Hl - 0.5f;
+          w = mw[l * P + p];
+        }
+        float gx = 0.f, gy = 0.f, gw = 0.f;
+        int64_t o[4] = {-1, -1, -1, -1};        // global line offsets (channel 0) of my corners
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live && y > -1.f && x > -1.f && y < Hl && x < Wl) {   // uniform over a half-wave
+          const Corner c = corners(x, y, Hl, Wl, base, row_stride);
+          const float d00 = ld1(vb, c.o00) * go, d01 = ld1(vb, c.o01) * go,
+                      d10 = ld1(vb, c.o10) * go, d11 = ld1(vb, c.o11) * go;
+          const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+          gw = c.w00 * d00 + c.w01 * d01 + c.w10 * d10 + c.w11 * d11;
+          gx = w * Wl * (-hh * d00 + hh * d01 - c.lh * d10 + c.lh * d11);
+          gy = w * Hl * (-hw * d00 - c.lw * d01 + hw * d10 + c.lw * d11);
+          const float wg = w * go;
+          if (c.o00 >= 0) { o[0] = gbase + c.o00; v[0] = c.w00 * wg; }
+          if (c.o01 >= 0) { o[1] = gbase + c.o01; v[1] = c.w01 * wg; }
+          if (c.o10 >= 0) { o[2] = gbase + c.o10; v[2] = c.w10 * wg; }
+          if (c.o11 >= 0) { o[3] = gbase + c.o11; v[3] = c.w11 * wg; }
+        }
+        // exchange with the partner half (same channel, other query)
+        int64_t po[4];
+        float pv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          po[j] = __shfl_xor((long long)o[j], kBLanes, 64);
+          pv[j] = __shfl_xor(v[j], kBLanes, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float total = v[i];
+          bool issue = o[i] >= 0;
+          if (half == 0) {                      // owner of shared lines: add the partner's share
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (issue && po[j] == o[i]) total += pv[j];
+          } else {                              // a line the lower half also writes is left to it
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (po[j] >= 0 && po[j] == o[i]) issue = false;
+          }
+          if (issue) unsafeAtomicAdd(gvb + o[i], total);
+        }
+        gx = half_wave_sum(gx); gy = half_wave_sum(gy); gw = half_wave_sum(gw);
+        if (ch == 0 && live) {
+          ml[(l * P + p) * 2] = gx;
+          ml[(l * P + p) * 2 + 1] = gy;
+          mw[l * P + p] = gw;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int half = 0; half < nhalf; ++half) {
+    const int64_t item_first = (bq0 + half) * H + h0;
+    const float* sl = s_loc + half * kPHeads * LP * 2;
+    const float* sw = s_w + half * kPHeads * LP;
+    for (int i = threadIdx.x; i < nh * LP * 2; i += kThreads) grad_loc[item_first * LP * 2 + i] = sl[i];
+    for (int i = threadIdx.x; i < nh * LP; i += kThreads) grad_w[item_first * LP + i] = sw[i];
+  }
+}
+
+int g_bwd_pair_merge = 0;
+
 inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
   return B < 0 || Nv < 0 || H <= 0 || C != kCh || Nq < 0 || L <= 0 || P <= 0 || L * P > kMaxLP;
 }
@@ -213,6 +340,12 @@ extern "C" {
 int vidar_msda_set_xcd_remap(int enabled) {
   const int v = enabled ? 0 : 1;
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_no_remap), &v, sizeof(int));
+}
+
+int vidar_msda_set_bwd_pair_merge(int enabled) {
+  const int prev = g_bwd_pair_merge;
+  g_bwd_pair_merge = enabled ? 1 : 0;
+  return prev;
 }
 
 int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
@@ -247,6 +380,17 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
   }
   const int64_t n_items = (int64_t)B * Nq * H;
   if (n_items == 0) return 0;
+  if (g_bwd_pair_merge) {
+    const int64_t n_bq = (int64_t)B * Nq;
+    const int n_hg = (H + kPHeads - 1) / kPHeads;
+    const int nb = (int)(((n_bq + 1) / 2) * n_hg);
+    const int grid_p = ((nb + 7) / 8) * 8;
+    const size_t lds_p = sizeof(float) * kPItems * L * P * 3;
+    hipLaunchKernelGGL(msda_bwd_pair_kernel, dim3(grid_p), dim3(kThreads), lds_p, s, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
+                       grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_bq, n_hg, nb);
+    return vidar_last_error();
+  }
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
   const int grid = ((nblocks + 7) / 8) * 8;
   const size_t lds = sizeof(float) * kBItems * L * P * 3;
