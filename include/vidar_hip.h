@@ -69,7 +69,8 @@ int vidar_dvxlr_max_d(void); /* 1026, third_lib/dvxlr/dvxlr.cu:10 */
  * Returns the previous value. */
 int vidar_dvr_set_sort_min_waves(int min_waves);
 /* tuning/A-B switch of dvxlr.render / render_v2: 0 = the finish pass pads the [1026] rows itself,
- * 1 = one device fill ahead of the march, the finish pass only touches the live prefixes.
+ * 1 (default) = one device fill ahead of the march, the finish pass only touches the live prefixes,
+ * 2 = like 1, with the fills of the rows the march never touches on a forked stream (unmeasured).
  * Results do not depend on it.  Returns the previous value. */
 int vidar_dvxlr_set_pad_mode(int mode);
 
