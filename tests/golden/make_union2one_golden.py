@@ -164,8 +164,22 @@ def main():
         d.update(lidar2ego_translation=o.data_infos[0]["lidar2ego_translation"],
                  lidar2ego_rotation=o.data_infos[0]["lidar2ego_rotation"], cam2img=d["cam_intrinsic"])
         infos_out[seed] = d
+    # nuPlan / OpenScene flavour (nuplan_vidar_dataset_template.py:48-118)
+    psrc = (REF / "nuplan_vidar_dataset_template.py").read_text()
+    a = psrc.index("        info = self.data_infos[index]\n        # standard protocal modified from SECOND.Pytorch")
+    b = psrc.index("        can_bus[-1] = patch_angle") + len("        can_bus[-1] = patch_angle")
+    import os
+    ns["os"] = os
+    exec("def get_data_info_nuplan(self, index):\n" + psrc[a:b] + "\n        return input_dict\n", ns)
+    infos_nuplan = {}
+    for seed in (0, 1):
+        o = type("O", (), {})()
+        rec = info_record(seed)
+        rec["sample_prev"], rec["sample_next"] = rec.pop("prev"), rec.pop("next")
+        o.data_infos, o.data_root = [rec], "data/openscene"
+        infos_nuplan[seed] = ns["get_data_info_nuplan"](o, 0)
     with open(HERE / "union2one.pkl", "wb") as fh:
-        pickle.dump(dict(infos=infos_out, cases=cases, scenes="AAAAAABBBBCCCCCCCCDD", scans=scans, lists=lists), fh, protocol=4)
+        pickle.dump(dict(infos=infos_out, infos_nuplan=infos_nuplan, cases=cases, scenes="AAAAAABBBBCCCCCCCCDD", scans=scans, lists=lists), fh, protocol=4)
     print("wrote union2one.pkl", {k: (None if v["ret"] is None else v["ret"]["gt_points"].shape) for k, v in cases.items()},
           len(scans), len(lists))
 

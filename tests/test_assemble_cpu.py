@@ -92,3 +92,22 @@ def test_frame_meta_from_info_matches_reference(gold, seed):
                                        err_msg=k)
         else:
             assert got[k] == w, k
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_frame_meta_from_nuplan_info_matches_reference(gold, seed):
+    from make_union2one_golden import info_record
+    from vidar_amd.data import frame_meta_from_info
+    rec = info_record(seed)
+    rec["sample_prev"], rec["sample_next"] = rec.pop("prev"), rec.pop("next")
+    got = frame_meta_from_info(rec, dataset="nuplan", data_root="data/openscene")
+    want = gold["infos_nuplan"][seed]
+    assert sorted(got) == sorted(want)
+    for k, w in want.items():
+        if isinstance(w, (list, np.ndarray)) and len(w) and not isinstance(w[0], str):
+            np.testing.assert_allclose(np.asarray(got[k], np.float64), np.asarray(w, np.float64), rtol=1e-12, atol=1e-12,
+                                       err_msg=k)
+        else:
+            assert got[k] == w, k
+    with pytest.raises(ValueError):
+        frame_meta_from_info(info_record(0), dataset="kitti")

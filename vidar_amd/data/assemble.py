@@ -43,23 +43,32 @@ def transform_matrix(translation, rotation, inverse: bool = False) -> np.ndarray
     return tm
 
 
-def frame_meta_from_info(info: dict) -> dict:
-    """nuScenes-style info dict (mmdet3d `nuscenes_infos_temporal_*.pkl` entry) -> the per-frame meta
-    the model and union2one read: lidar2img per camera, lidar2global_rotation, can_bus with the
-    pose patched in (CustomNuScenesDataset.get_data_info, datasets/nuscenes_dataset.py:153-227, plus
-    the lidar2ego / cam2img fields of the template's override, nuscenes_vidar_dataset_template.py:70-80)."""
+def frame_meta_from_info(info: dict, dataset: str = "nuscenes", data_root: str = "") -> dict:
+    """info dict (entry of the mmdet3d-style `*_infos_*.pkl`) -> the per-frame meta the model and
+    union2one read: lidar2img per camera, lidar2global_rotation, can_bus with the pose patched in.
+    dataset="nuscenes": CustomNuScenesDataset.get_data_info (datasets/nuscenes_dataset.py:153-227) plus
+    the lidar2ego / cam2img fields of the template's override (nuscenes_vidar_dataset_template.py:70-80);
+    dataset="nuplan" (OpenScene): NuPlanViDARDatasetTemplate.get_data_info
+    (nuplan_vidar_dataset_template.py:48-118) -- paths joined with data_root, sample_prev/next, no sweeps."""
+    import os
+    if dataset not in ("nuscenes", "nuplan"):
+        raise ValueError(f"unknown dataset flavour {dataset!r}")
+    nuplan = dataset == "nuplan"
     lidar2ego_r = _rotation_matrix(info["lidar2ego_rotation"])
     ego2global_r = _rotation_matrix(info["ego2global_rotation"])
-    meta = dict(sample_idx=info["token"], pts_filename=info["lidar_path"], sweeps=info["sweeps"],
+    meta = dict(sample_idx=info["token"],
+                pts_filename=os.path.join(data_root, info["lidar_path"]) if nuplan else info["lidar_path"],
+                sweeps=[] if nuplan else info["sweeps"],
                 ego2global_translation=info["ego2global_translation"],
                 ego2global_rotation=info["ego2global_rotation"],
-                lidar2global_rotation=ego2global_r @ lidar2ego_r, prev_idx=info["prev"], next_idx=info["next"],
+                lidar2global_rotation=ego2global_r @ lidar2ego_r,
+                prev_idx=info["sample_prev" if nuplan else "prev"], next_idx=info["sample_next" if nuplan else "next"],
                 scene_token=info["scene_token"], can_bus=info["can_bus"], frame_idx=info["frame_idx"],
                 timestamp=info["timestamp"] / 1e6, lidar2ego_translation=info["lidar2ego_translation"],
                 lidar2ego_rotation=info["lidar2ego_rotation"])
     paths, lidar2img, intrinsics, lidar2cam = [], [], [], []
     for cam in info["cams"].values():
-        paths.append(cam["data_path"])
+        paths.append(os.path.join(data_root, cam["data_path"]) if nuplan else cam["data_path"])
         r = np.linalg.inv(cam["sensor2lidar_rotation"])
         t = cam["sensor2lidar_translation"] @ r.T
         rt = np.eye(4)
@@ -71,8 +80,9 @@ def frame_meta_from_info(info: dict) -> dict:
         lidar2img.append(viewpad @ rt.T)
         intrinsics.append(viewpad)
         lidar2cam.append(rt.T)
-    meta.update(img_filename=paths, lidar2img=lidar2img, cam_intrinsic=intrinsics, lidar2cam=lidar2cam,
-                cam2img=intrinsics)
+    meta.update(img_filename=paths, lidar2img=lidar2img, lidar2cam=lidar2cam, cam2img=intrinsics)
+    if not nuplan:
+        meta["cam_intrinsic"] = intrinsics
     # overwrite the can-bus pose with the ego pose; yaw in [0, 360) degrees / radians
     can_bus = meta["can_bus"]
     can_bus[:3] = info["ego2global_translation"]
