@@ -184,7 +184,8 @@ def bench_ray(which):
     g = torch.ones_like(ce)
     ms = timeit(lambda: torch.autograd.grad(ce, sigma, g, retain_graph=True))
     report("ray_ce_bwd P=30000", ms, 4 * (2 * 16 * 200 * 200 + 30000 * 5))
-    from tests_dense import dense_rays
+    sys.path.insert(0, str(ROOT / 'tests'))
+    from test_ray_ops_gpu import dense_rays
     pts, tix = dense_rays(1, 16, 200, 200, "cuda")
     noise = gumbel_noise(pts.shape[0], 512)
     ms = timeit(lambda: ray_gumbel(sigma, o, pts, tix, noise))
