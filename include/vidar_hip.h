@@ -136,22 +136,25 @@ int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
  * bwd: grad_value is zeroed by the call then accumulated with fp32 atomics; grad_sampling_loc and
  * grad_attn_weight are fully written (the reference expects pre-zeroed buffers, function.py:146-148).
  * ------------------------------------------------------------------------- */
-/* tuning/A-B switch: 1 (default) = XCD-banded workgroup order, 0 = plain blockIdx order */
-int vidar_msda_set_xcd_remap(int enabled);
-/* tuning/A-B switch of the backward scatter: 1 = the two half-waves of a wave own the same head of two
- * adjacent queries and write the corner lines they share once (fewer atomic requests), 0 (default) =
- * one (query, head) item per half-wave, every corner line written.  Results differ only in fp32
- * summation order.  Returns the previous value. */
-int vidar_msda_set_bwd_pair_merge(int enabled);
 int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq,
                        int L, int P, void* stream);
+/* bwd has two scatter strategies for grad_value, chosen by the caller through `workspace`:
+ *   workspace == NULL : one fp32 atomic per (sample, corner) 128-byte line (fine for small launches);
+ *   workspace != NULL : samples are counting-sorted by destination tile (batch, level, 8x8 pixels, head)
+ *                       into the workspace, accumulated per tile in LDS and flushed with one atomic per
+ *                       non-zero window line (see csrc/msda.hip).  The workspace needs
+ *                       vidar_msda_bwd_workspace_bytes(...) bytes (0 = shape not supported by this
+ *                       strategy: more than 16 levels or >= 2^31 samples), is scratch (no state survives the
+ *                       call) and must stay alive until the stream has run the call.
+ * Both give the same result up to fp32 summation order. */
+size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P);
 int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, const float* grad_out, float* grad_value,
                        float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
-                       int Nq, int L, int P, void* stream);
+                       int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * LatentRendering ray-march (fused).  Replaces the torch op chain of

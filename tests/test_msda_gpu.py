@@ -14,16 +14,19 @@ CASES = [
     ("pred_small", 1, [(16, 12)], 192, 4),
     ("one", 1, [(1, 1)], 1, 1),
     ("ragged_items", 1, [(9, 7)], 5, 4),          # 40 items: last workgroup partially filled
-    ("bev_self_attn_tiled", 2, [(24, 24)], 576, 4),   # Nv == Nq square grid -> 8x8 tiled write-combining path
-    ("bev_ragged_tiles", 1, [(20, 20)], 400, 4),      # grid not a multiple of the 8x8 tile
-    ("sca_wc", 2, [(30, 50), (15, 25), (8, 13), (4, 7)], 1000, 8),  # multi-level write-combining path
+    ("bev_self_attn", 2, [(24, 24)], 576, 4),         # Nv == Nq square grid (tile edge 8 divides the grid)
+    ("bev_ragged_tiles", 1, [(20, 20)], 400, 4),      # grid not a multiple of the 8x8 destination tile
+    ("sca_mid", 2, [(30, 50), (15, 25), (8, 13), (4, 7)], 1000, 8),  # multi-level, several chunks per tile
+    ("two_heads", 2, [(12, 20), (6, 10)], 144, 8, 2),  # the golden models' width: embed 64 = 2 heads
+    ("hot_tile", 1, [(3, 3)], 5000, 8),                # > 1024 samples per destination tile -> several chunks
 ]
+SCATTER = {"atomic": False, "binned": True}
 
 
-def run(B, shapes, Nq, P, seed=0):
-    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import \
-        MultiScaleDeformableAttnFunction_fp32 as F32
-    value, sh, loc, w = M.make_case(seed, B, shapes, Nq, P=P)
+def run(B, shapes, Nq, P, H=8, seed=0, binned=None):
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    F32 = F.MultiScaleDeformableAttnFunction_fp32
+    value, sh, loc, w = M.make_case(seed, B, shapes, Nq, H=H, P=P)
     v64, l64, w64 = value.double().requires_grad_(True), loc.double().requires_grad_(True), \
         w.double().requires_grad_(True)
     ref = M.msda_gather(v64, sh, l64, w64)
@@ -32,13 +35,20 @@ def run(B, shapes, Nq, P, seed=0):
     dv, dl, dw = value.cuda().requires_grad_(True), loc.cuda().requires_grad_(True), \
         w.cuda().requires_grad_(True)
     out = F32.apply(dv, sh.cuda(), M.level_start_index(shapes).cuda(), dl, dw, 64)
-    got = torch.autograd.grad((out * gout.float().cuda()).sum(), [dv, dl, dw])
+    if binned is None:
+        got = torch.autograd.grad((out * gout.float().cuda()).sum(), [dv, dl, dw])
+    else:        # the scatter strategy is the caller's choice (workspace or not, include/vidar_hip.h)
+        got = F._msda_backward(dv.detach(), sh.cuda(), M.level_start_index(shapes).cuda(), dl.detach(),
+                               dw.detach(), gout.float().cuda(), binned=binned)
     return ref, gref, out, got
 
 
-@pytest.mark.parametrize("name,B,shapes,Nq,P", CASES)
-def test_msda_fwd_bwd(name, B, shapes, Nq, P):
-    ref, gref, out, got = run(B, shapes, Nq, P)
+@pytest.mark.parametrize("scatter", list(SCATTER))
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_msda_fwd_bwd(case, scatter):
+    name, B, shapes, Nq, P = case[:5]
+    H = case[5] if len(case) > 5 else 8
+    ref, gref, out, got = run(B, shapes, Nq, P, H=H, binned=SCATTER[scatter])
     torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-4, atol=1e-5)
     for g, r, nm in zip(got, gref, ["grad_value", "grad_loc", "grad_w"]):
         scale = max(1.0, float(r.abs().max()))
@@ -67,3 +77,72 @@ def test_full_size_tsa_linearity():
     inside = loc.clamp(0.05, 0.95)              # constant field + interior samples -> sum of weights
     c = f(ones, sh, lsi, inside, w)
     torch.testing.assert_close(c, w.sum((3, 4)).repeat_interleave(32, -1).view_as(c), rtol=1e-5, atol=1e-5)
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def _full_case(name):
+    B, shapes, Nq, P = FULL[name]
+    value, sh, loc, w = M.make_case(11, B, shapes, Nq, P=P)
+    gout = torch.randn(B, Nq, 256, generator=torch.Generator().manual_seed(12))
+    return value, sh, loc, w, gout, _oracle_fwd_bwd_per_batch(value, sh, loc, w, gout)
+
+
+def _oracle_fwd_bwd_per_batch(value, sh, loc, w, gout):
+    """fp64 grid_sample formulation, one batch element at a time (memory)."""
+    outs, gv, gl, gw = [], [], [], []
+    for b in range(value.shape[0]):
+        v, l_, w_ = (t[b:b + 1].double().requires_grad_(True) for t in (value, loc, w))
+        o = M.msda_grid_sample(v, sh, l_, w_)
+        g = torch.autograd.grad((o * gout[b:b + 1].double()).sum(), [v, l_, w_])
+        outs.append(o.detach()); gv.append(g[0]); gl.append(g[1]); gw.append(g[2])
+    return torch.cat(outs), torch.cat(gv), torch.cat(gl), torch.cat(gw)
+
+
+FULL = {
+    # BASELINE config 1 shapes (SURVEY 8a1): TSA B=2 200x200 P=4; SCA B=6 cams, 4 FPN levels of the
+    # 928x1600 image (Nv=30 825), max_len 10^4 visible queries, P=8; Prediction B=1 200x200 P=4
+    "tsa_200x200": (2, [(200, 200)], 40000, 4),
+    "sca_6cam_fpn": (6, [(116, 200), (58, 100), (29, 50), (15, 25)], 10000, 8),
+    "pred_200x200": (1, [(200, 200)], 40000, 4),
+}
+
+
+@pytest.mark.parametrize("scatter", list(SCATTER))
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_matches_oracle(name, scatter):
+    """HIP forward + backward against the fp64 oracle at the BASELINE shapes (both scatter strategies)."""
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    B, shapes, Nq, P = FULL[name]
+    value, sh, loc, w, gout, (ref, rv, rl, rw) = _full_case(name)
+    lsi = M.level_start_index(shapes).cuda()
+    dv, dl, dw = value.cuda(), loc.cuda(), w.cuda()
+    out = F._msda_forward(dv, sh.cuda(), lsi, dl, dw)
+    # tolerance at 200-pixel-wide levels: the fp32 pixel coordinate loc*W-0.5 carries ulp(200)/2 = 7.6e-6
+    # of rounding that the fp64 oracle does not have; times |d value / d pixel| ~ 3 (unit-variance value)
+    # -> a few 1e-5 absolute on outputs of magnitude ~1 (the fp32 reference kernel has the same rounding)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+    got = F._msda_backward(dv, sh.cuda(), lsi, dl, dw, gout.cuda(), binned=SCATTER[scatter])
+    for g, r, nm in zip(got, (rv, rl, rw), ["grad_value", "grad_loc", "grad_w"]):
+        scale = max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(g.cpu().double(), r, rtol=2e-4, atol=1e-4 * scale, msg=lambda m: nm + m)
+
+
+def test_binned_workspace_contract():
+    """workspace too small -> invalid argument; unsupported level count -> 0 bytes (caller falls back)."""
+    import ctypes
+    from vidar_amd._lib import lib, ptr, stream_of
+    f = lib().vidar_msda_bwd_workspace_bytes
+    f.restype = ctypes.c_size_t
+    assert f(2, 400, 8, 400, 1, 4) > 0
+    assert f(1, 400, 8, 400, 17, 1) == 0
+    value, sh, loc, w = M.make_case(0, 2, [(20, 20)], 400, P=4)
+    a = [t.cuda() for t in (value, sh, M.level_start_index([(20, 20)]), loc, w)]
+    go = torch.zeros(2, 400, 256, device="cuda")
+    gv, gl, gw = torch.empty_like(a[0]), torch.empty_like(a[3]), torch.empty_like(a[4])
+    ws = torch.empty(8, dtype=torch.int64, device="cuda")
+    rc = lib().vidar_msda_bwd_f32(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(go), ptr(gv), ptr(gl),
+                                  ptr(gw), 2, 400, 8, 32, 400, 1, 4, ptr(ws), ctypes.c_size_t(64), stream_of(go))
+    assert rc == -22

@@ -89,22 +89,11 @@ def bench_knn(which):
                fp32_TFLOPs=round(P1 * P2 * 8 / ms / 1e9, 2))
 
 
-def bench_msda_ab(which):
-    """XCD-banded vs plain workgroup order (A/B)."""
-    from vidar_amd._lib import lib
-    for flag in (1, 0, 1, 0):
-        lib().vidar_msda_set_xcd_remap(flag)
-        print(json.dumps({"xcd_remap": flag}))
-        bench_msda(which)
-    lib().vidar_msda_set_xcd_remap(1)
-
-
-def bench_msda_pair(which):
-    """A/B of the pair-merging backward scatter (vidar_msda_set_bwd_pair_merge) on spatially coherent
-    queries (what the model produces: neighbouring BEV queries sample next to each other; the random
-    reference points of `bench_msda` share no lines) + agreement of both kernels."""
+def bench_msda_coherent(which):
+    """both scatter strategies of msda_bwd on spatially coherent queries (what the model produces:
+    neighbouring BEV queries sample next to each other; the random reference points of `bench_msda`
+    share no lines) + their agreement."""
     from oracle import msda as M   # operand generator only (bench tool, not product)
-    from vidar_amd._lib import lib
     from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_backward
     fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
     for name, B, shapes, Nq, P, px in (("TSA-like", 2, [(200, 200)], 40000, 4, 1.0),
@@ -123,13 +112,11 @@ def bench_msda_pair(which):
         lsi = M.level_start_index(shapes).cuda()
         go = torch.randn(B, Nq, 256, device="cuda")
         outs = {}
-        for flag in (0, 1):
-            lib().vidar_msda_set_bwd_pair_merge(flag)
-            outs[flag] = _msda_backward(value, sh, lsi, loc, w, go)
-            ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go))
-            report(f"msda_bwd {name} pair_merge={flag}", ms)
-        lib().vidar_msda_set_bwd_pair_merge(0)
-        for a, b, nm in zip(outs[0], outs[1], ("grad_value", "grad_loc", "grad_w")):
+        for binned in (False, True):
+            outs[binned] = _msda_backward(value, sh, lsi, loc, w, go, binned=binned)
+            ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=binned))
+            report(f"msda_bwd {name} binned={binned}", ms)
+        for a, b, nm in zip(outs[False], outs[True], ("grad_value", "grad_loc", "grad_w")):
             print(json.dumps({"agreement": nm, "max_abs_diff": float((a - b).abs().max()),
                               "scale": float(a.abs().max())}), flush=True)
 
@@ -148,8 +135,9 @@ def bench_msda(which):
         ms = timeit(lambda: _msda_forward(value, sh, lsi, loc, w))
         report(f"msda_fwd {name}", ms, fwd_bytes)
         go = torch.randn(B, Nq, 256, device="cuda")
-        ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go))
-        report(f"msda_bwd {name}", ms, fwd_bytes + 4 * (B * Nq * 256 + B * Nv * 256 + B * Nq * 8 * L * P * 3))
+        for binned in (False, True):
+            ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=binned))
+            report(f"msda_bwd {name} binned={binned}", ms, fwd_bytes + 4 * (B * Nq * 256 + B * Nv * 256 + B * Nq * 8 * L * P * 3))
 
 
 def bench_lr(which):

@@ -33,13 +33,17 @@ constexpr int kThreads = 256;
 constexpr int kItems = kThreads / kLanes;  // 32 items per workgroup
 constexpr int kMaxLP = 64;         // max levels*points staged per item
 
-__device__ int g_no_remap = 0;   // A/B switch for tools/kbench.py (VIDAR_NO_XCD_REMAP=1)
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-  // blocks are dealt round-robin to the 8 XCDs; give XCD k the k-th contiguous band
-  if (g_no_remap) return bid;
+  // blocks are dealt round-robin to the 8 XCDs; give XCD k the k-th contiguous band (measured within
+  // 1 % of plain order on random reference points, profiles/r01_kbench_msda_xcd_remap_ab.log; kept for
+  // the spatially coherent queries the model produces)
   const int per = (nblocks + 7) >> 3;
   return (bid & 7) * per + (bid >> 3);
 }
+
+// pixel coordinate of a normalised location: ONE rounding (fma), the same in every kernel -- the
+// binned backward computes the tile of a sample in one kernel and its window offset in another
+__device__ __forceinline__ float pix(float v, int n) { return __fmaf_rn(v, (float)n, -0.5f); }
 
 struct Corner {
   int64_t o00, o01, o10, o11;  // element offsets (in floats) or -1
@@ -99,8 +103,8 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
     const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
     const int64_t base = lsi[l] * row_stride;
     for (int p = 0; p < P; ++p) {
-      const float x = ml[(l * P + p) * 2] * Wl - 0.5f;
-      const float y = ml[(l * P + p) * 2 + 1] * Hl - 0.5f;
+      const float x = pix(ml[(l * P + p) * 2], Wl);
+      const float y = pix(ml[(l * P + p) * 2 + 1], Hl);
       const float w = mw[l * P + p];
       if (y > -1.f && x > -1.f && y < Hl && x < Wl) {
         const Corner c = corners(x, y, Hl, Wl, base, row_stride);
@@ -169,8 +173,8 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
       const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
       const int64_t base = lsi[l] * row_stride;
       for (int p = 0; p < P; ++p) {
-        const float x = ml[(l * P + p) * 2] * Wl - 0.5f;
-        const float y = ml[(l * P + p) * 2 + 1] * Hl - 0.5f;
+        const float x = pix(ml[(l * P + p) * 2], Wl);
+        const float y = pix(ml[(l * P + p) * 2 + 1], Hl);
         const float w = mw[l * P + p];
         float gx = 0.f, gy = 0.f, gw = 0.f;
         if (y > -1.f && x > -1.f && y < Hl && x < Wl) {     // uniform over the item's 32 lanes
@@ -203,113 +207,286 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, pair-merging variant (A/B switch vidar_msda_set_bwd_pair_merge, default off until it has
-// been measured).  The scatter sits on the atomic-unit wall (one request per instruction x 128-byte
-// line), so the only lever is fewer requests.  Here the two half-waves of a wave own the SAME head of
-// two ADJACENT queries (bq, bq+1): neighbouring BEV queries project next to each other, and on the
-// coarse pyramid levels / for far queries the same (level, point) sample of both lands in the same
-// pixel cell or in cells that share an edge.  The half-waves exchange their four corner line ids and
-// values by shuffle; a line both of them touch is written once, by the lower half, with the sum.
-// Results differ from the plain kernel only in fp32 summation order.
-// Workgroup = 4 waves = 4 heads x 2 queries; grid = ceil(B*Nq/2) query pairs x ceil(H/4) head groups.
+// backward, destination-binned variant (the default for launches big enough to amortise 5 launches).
+// Measured on MI355X (tools/micro/{atomic_scope_bench,scatter_bench}.hip, profiles/r02_micro.log):
+//   * global fp32 atomics retire at ~9-10 G (instruction x 128-byte line) requests/s no matter the
+//     scope or whether the target is an XCD-private copy  -> the scatter above is on that wall;
+//   * LDS ds_add_f32 is no faster (6 G line-adds/s), scattered 4-byte stores run at 85 G/s and random
+//     128-byte line gathers at 56 G lines/s (7 TB/s out of L2/MALL).
+// So the scatter becomes: counting-sort the (b,q,head,level,point) samples by DESTINATION tile
+// (batch, level, 8x8 block of top-left corner pixels, head), then one wave per <=1024-sample chunk of
+// a tile accumulates the 9x9-pixel x 32-channel window of that tile in its PRIVATE 10 KB LDS window
+// with plain (non-atomic) read-modify-writes -- all 64 lanes work on ONE sample: lanes 0-31 own the 32
+// channels of the left corner column, lanes 32-63 the right column, top row then bottom row, so the
+// 64 addresses of a step are always distinct and a wave's LDS operations execute in order -- and
+// flushes the non-zero window lines with one atomic per line: ~2-3 M requests instead of 61 M.
+// grad_loc / grad_w come from a gather kernel shaped like the forward (no atomics at all).
 // ---------------------------------------------------------------------------------------------
-constexpr int kPHeads = kThreads / 64;         // heads per workgroup (one wave each)
-constexpr int kPItems = 2 * kPHeads;           // LDS slots: [half][head]
+constexpr int kTile = 8;                       // tile edge (top-left corner pixels)
+constexpr int kWin = kTile + 1;                // window edge (corner pixels)
+constexpr int kWinLines = kWin * kWin;         // 81 lines of 32 floats
+constexpr int kChunk = 1024;                   // samples per wave
+constexpr int kMaxL = 16;                      // levels supported by the binned path
+constexpr int kTWaves = 2;                     // waves (= chunks) per workgroup of the tile kernel
 
-__global__ __launch_bounds__(kThreads) void msda_bwd_pair_kernel(
-    const float* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
-    const float* __restrict__ grad_out, float* __restrict__ grad_value,
-    float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv, int H, int Nq, int L, int P,
-    int64_t n_bq, int n_hg, int nblocks) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LP = L * P;
-  float* s_loc = smem;                         // [kPItems][LP*2]  in: loc, out: grad_loc
-  float* s_w = smem + kPItems * LP * 2;        // [kPItems][LP]    in: w,   out: grad_w
-  const int blk = xcd_remap(blockIdx.x, nblocks);
-  if (blk >= nblocks) return;
-  const int64_t pair = blk / n_hg;
-  const int h0 = (blk % n_hg) * kPHeads;       // first head of this workgroup
-  const int nh = min(kPHeads, H - h0);         // valid heads here
-  const int64_t bq0 = pair * 2;
-  const int nhalf = (bq0 + 1 < n_bq) ? 2 : 1;  // valid queries here
-  // staging: per half one contiguous run of nh items (heads h0 .. h0+nh-1 of query bq0+half)
-  for (int half = 0; half < nhalf; ++half) {
-    const int64_t item_first = (bq0 + half) * H + h0;
-    float* dl = s_loc + half * kPHeads * LP * 2;
-    float* dw = s_w + half * kPHeads * LP;
-    for (int i = threadIdx.x; i < nh * LP * 2; i += kThreads) dl[i] = loc[item_first * LP * 2 + i];
-    for (int i = threadIdx.x; i < nh * LP; i += kThreads) dw[i] = attw[item_first * LP + i];
+struct LevelTab {
+  int Hl[kMaxL], Wl[kMaxL], ntx[kMaxL], toff[kMaxL];
+  int T;                                       // tiles per batch element
+};
+
+__device__ __forceinline__ void build_tab(LevelTab& t, const int64_t* __restrict__ shapes, int L) {
+  if (threadIdx.x == 0) {
+    int off = 0;
+    for (int l = 0; l < L; ++l) {
+      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+      t.Hl[l] = Hl; t.Wl[l] = Wl; t.ntx[l] = (Wl >> 3) + 1; t.toff[l] = off;
+      off += t.ntx[l] * ((Hl >> 3) + 1);       // px = floor(x)+1 in [0, Wl], py likewise
+    }
+    t.T = off;
   }
   __syncthreads();
-  const int wv = threadIdx.x / 64, lane = threadIdx.x % 64;
-  const int half = lane / kBLanes, ch = lane % kBLanes;
-  if (wv < nh) {                                // wave-uniform: both halves take part in the shuffles
-    const bool live = half < nhalf;
-    const int64_t bq = bq0 + (live ? half : 0);
-    const int h = h0 + wv;
-    const int b = (int)(bq / Nq);
+}
+
+// tile (within its level) of a sample, or -1 when the sample falls outside the level -- exactly the
+// test of the forward
+__device__ __forceinline__ int sample_tile(const LevelTab& t, const float* __restrict__ loc, int64_t s, int l) {
+  const float2 xy = reinterpret_cast<const float2*>(loc)[s];
+  const int Hl = t.Hl[l], Wl = t.Wl[l];
+  const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
+  if (!(y > -1.f && x > -1.f && y < Hl && x < Wl)) return -1;
+  const int px = (int)floorf(x) + 1, py = (int)floorf(y) + 1;
+  return (py >> 3) * t.ntx[l] + (px >> 3);
+}
+
+// Counting sort, passes 1 and 3.  Global int atomics on the tile counters would put the sort on the
+// same atomic wall as the scatter it replaces (measured: 3.9 + 6.8 ms for the 15 M samples of SCA, hot
+// tiles serialise).  So a workgroup owns kBinQ consecutive queries of ONE (batch, head, level) plane --
+// its samples can only fall into that level's tiles -- histograms them in LDS and touches the global
+// counters once per (workgroup, touched tile).
+constexpr int kBinQ = 512;                     // queries per workgroup
+constexpr int kBinSamples = 16;                // samples per thread held in registers (fill pass)
+constexpr int kMaxTilesLds = 8192;             // LDS histogram capacity (tiles of one level)
+
+template <bool FILL>
+__global__ __launch_bounds__(kThreads) void msda_bin_kernel(
+    const int64_t* __restrict__ shapes, const float* __restrict__ loc, int* __restrict__ counts,
+    int* __restrict__ rec, int H, int Nq, int L, int P) {
+  extern __shared__ int s_hist[];              // [ntl] counts, then (FILL) [ntl] base slots
+  __shared__ LevelTab t;
+  build_tab(t, shapes, L);
+  const int plane = blockIdx.y;                // (b * H + h) * L + l
+  const int l = plane % L, h = (plane / L) % H, b = plane / L / H;
+  const int ntl = t.ntx[l] * ((t.Hl[l] >> 3) + 1);
+  const int q0 = blockIdx.x * kBinQ, nq = min(kBinQ, Nq - q0);
+  const int n = nq * P;                        // samples of this workgroup
+  const int LP = L * P;
+  int* s_base = s_hist + ntl;
+  for (int i = threadIdx.x; i < ntl; i += kThreads) s_hist[i] = 0;
+  __syncthreads();
+  const int64_t gbin0 = ((int64_t)b * t.T + t.toff[l]) * H + h;    // bin = gbin0 + tile * H
+  int tile_of[kBinSamples];
+  for (int i0 = 0; i0 < n; i0 += kThreads * kBinSamples) {
+#pragma unroll
+    for (int u = 0; u < kBinSamples; ++u) {
+      const int i = i0 + u * kThreads + threadIdx.x;
+      int tl = -1;
+      if (i < n) {
+        const int ql = i / P, p = i - ql * P;
+        tl = sample_tile(t, loc, (((int64_t)b * Nq + q0 + ql) * H + h) * LP + l * P + p, l);
+        if (tl >= 0) atomicAdd(s_hist + tl, 1);
+      }
+      tile_of[u] = tl;
+    }
+    if (!FILL) continue;
+    __syncthreads();
+    // reserve a run of record slots per touched tile (the cursor was initialised with the bin starts)
+    for (int i = threadIdx.x; i < ntl; i += kThreads) {
+      const int c = s_hist[i];
+      if (c) { s_base[i] = atomicAdd(counts + gbin0 + (int64_t)i * H, c); s_hist[i] = 0; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kBinSamples; ++u) {
+      const int i = i0 + u * kThreads + threadIdx.x;
+      const int tl = tile_of[u];
+      if (tl >= 0) {
+        const int ql = i / P, p = i - ql * P;
+        rec[s_base[tl] + atomicAdd(s_hist + tl, 1)] =
+            (int)((((int64_t)b * Nq + q0 + ql) * H + h) * LP + l * P + p);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntl; i += kThreads) s_hist[i] = 0;   // next batch of this workgroup
+    __syncthreads();
+  }
+  if (FILL) return;
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntl; i += kThreads) {
+    const int c = s_hist[i];
+    if (c) atomicAdd(counts + gbin0 + (int64_t)i * H, c);
+  }
+}
+
+// one workgroup: counts -> exclusive prefix (left in `counts`, it becomes the fill cursor) and the
+// chunk table {bin, first record, number of records}
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
+    const int64_t* __restrict__ shapes, int* __restrict__ counts, int4* __restrict__ desc,
+    int* __restrict__ n_chunks, int B, int H, int L) {
+  __shared__ LevelTab t;
+  __shared__ int s_sum[kScanThreads], s_chk[kScanThreads];
+  build_tab(t, shapes, L);
+  const int nbins = B * t.T * H;
+  const int per = (nbins + kScanThreads - 1) / kScanThreads;
+  const int r0 = min(nbins, (int)threadIdx.x * per), r1 = min(nbins, r0 + per);
+  int cs = 0, cc = 0;
+  for (int b = r0; b < r1; ++b) { const int c = counts[b]; cs += c; cc += (c + kChunk - 1) / kChunk; }
+  s_sum[threadIdx.x] = cs; s_chk[threadIdx.x] = cc;
+  __syncthreads();
+  for (int d = 1; d < kScanThreads; d <<= 1) {        // Hillis-Steele inclusive scan
+    int a = 0, c = 0;
+    if ((int)threadIdx.x >= d) { a = s_sum[threadIdx.x - d]; c = s_chk[threadIdx.x - d]; }
+    __syncthreads();
+    s_sum[threadIdx.x] += a; s_chk[threadIdx.x] += c;
+    __syncthreads();
+  }
+  int s = s_sum[threadIdx.x] - cs, k = s_chk[threadIdx.x] - cc;
+  for (int b = r0; b < r1; ++b) {
+    const int c = counts[b];
+    counts[b] = s;
+    for (int i = 0; i < c; i += kChunk) desc[k++] = make_int4(b, s + i, min(kChunk, c - i), 0);
+    s += c;
+  }
+  if (threadIdx.x == kScanThreads - 1) *n_chunks = s_chk[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+    const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
+    const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
+    int H, int L, int P) {
+  __shared__ LevelTab t;
+  __shared__ float s_win[kTWaves][kWinLines * kCh];
+  build_tab(t, shapes, L);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * kTWaves + wave;
+  if (chunk >= *n_chunks) return;                      // wave-uniform
+  const int4 d = desc[chunk];
+  const int bin = d.x, s0 = d.y, n = d.z;
+  const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
+  int l = 0;
+  while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
+  const int Hl = t.Hl[l], Wl = t.Wl[l];
+  const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
+  float* win = s_win[wave];
+  for (int i = lane; i < kWinLines * kCh; i += 64) win[i] = 0.f;
+  const int LP = L * P;
+  const int rmask = lane >= 32 ? -1 : 0;
+  for (int base = 0; base < n; base += 64) {
+    // lane k prepares sample base+k: window offset of its top-left corner, the four corner weights
+    // (times the attention weight) and the offset of its grad_out line
+    const bool valid = base + lane < n;
+    const int s = rec[s0 + (valid ? base + lane : 0)];
+    const float2 xy = reinterpret_cast<const float2*>(loc)[s];
+    const float aw = valid ? attw[s] : 0.f;
+    const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
+    const int h0 = (int)floorf(y), w0 = (int)floorf(x);
+    const float lh = y - h0, lw = x - w0;
+    const float wl_top = (1.f - lh) * (1.f - lw) * aw, wr_top = (1.f - lh) * lw * aw;
+    const float wl_bot = lh * (1.f - lw) * aw, wr_bot = lh * lw * aw;
+    const int off = (min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1)) * kCh;
+    const int gofs = (s / LP) * kCh;
+    const int m = min(64, n - base);
+#pragma unroll
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      if (j0 >= m) break;                              // wave-uniform
+      float g[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        g[u] = grad_out[__builtin_amdgcn_readlane(gofs, j0 + u) + (lane & 31)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u;
+        // lanes 0-31 take the left-column weights, 32-63 the right-column ones (bit select, no branch)
+        const float a_top = __int_as_float((__builtin_amdgcn_readlane(__float_as_int(wl_top), j) & ~rmask) |
+                                           (__builtin_amdgcn_readlane(__float_as_int(wr_top), j) & rmask));
+        const float a_bot = __int_as_float((__builtin_amdgcn_readlane(__float_as_int(wl_bot), j) & ~rmask) |
+                                           (__builtin_amdgcn_readlane(__float_as_int(wr_bot), j) & rmask));
+        float* p = win + __builtin_amdgcn_readlane(off, j) + lane;   // + 32 for the right column
+        const float t0 = p[0], t1 = p[kWin * kCh];
+        p[0] = t0 + a_top * g[u];
+        p[kWin * kCh] = t1 + a_bot * g[u];
+      }
+    }
+  }
+  // flush: window line i = (row r, column c) is pixel (ty*8 + r - 1, tx*8 + c - 1)
+  const int ch = lane & 31;
+  float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
+  for (int i = lane >> 5; i < kWinLines; i += 2) {
+    const int r = i / kWin, c = i - r * kWin;
+    const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
+    if (py < 0 || py >= Hl || px < 0 || px >= Wl) continue;
+    const float v = win[i * kCh + ch];
+    if (v != 0.f) unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
+  }
+}
+
+// grad_sampling_loc / grad_attn_weight: a gather shaped like the forward (8 lanes x float4 per
+// (b,q,head) item, dot products reduced over the 8 lanes by xor shuffles), results leave through the
+// LDS staging area as coalesced stores.  No atomics.
+__global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
+    const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv,
+    int H, int Nq, int L, int P, int64_t n_items, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int LP = L * P;
+  float* s_loc = smem;                       // [kItems][LP*2]  in: loc, out: grad_loc
+  float* s_w = smem + kItems * LP * 2;       // [kItems][LP]    in: w,   out: grad_w
+  const int blk = xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;
+  const int64_t item0 = (int64_t)blk * kItems;
+  const int nvalid = (int)min((int64_t)kItems, n_items - item0);
+  for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) s_loc[i] = loc[item0 * LP * 2 + i];
+  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) s_w[i] = attw[item0 * LP + i];
+  __syncthreads();
+  const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
+  if (it < nvalid) {
+    const int64_t item = item0 + it;
+    const int h = (int)(item % H);
+    const int b = (int)(item / H / Nq);
     const int row_stride = H * kCh;
-    const int64_t item = bq * H + h;
-    const int64_t gbase = (int64_t)b * Nv * row_stride + h * kCh;   // element offset of channel 0
-    const float* vb = value + gbase + ch;
-    float* gvb = grad_value + ch;               // + global line offset below
-    const float go = live ? grad_out[item * kCh + ch] : 0.f;
-    const int slot = half * kPHeads + wv;
-    float* ml = s_loc + slot * LP * 2;
-    float* mw = s_w + slot * LP;
+    const float* vb = value + (int64_t)b * Nv * row_stride + h * kCh + sub * 4;
+    const float4 go = *reinterpret_cast<const float4*>(grad_out + item * kCh + sub * 4);
+    float* ml = s_loc + it * LP * 2;
+    float* mw = s_w + it * LP;
     for (int l = 0; l < L; ++l) {
       const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
       const int64_t base = lsi[l] * row_stride;
       for (int p = 0; p < P; ++p) {
-        float x = 0.f, y = 0.f, w = 0.f;
-        if (live) {
-          x = ml[(l * P + p) * 2] * Wl - 0.5f;
-          y = ml[(l * P + p) * 2 + 1] * Hl - 0.5f;
-          w = mw[l * P + p];
-        }
+        const float x = pix(ml[(l * P + p) * 2], Wl);
+        const float y = pix(ml[(l * P + p) * 2 + 1], Hl);
+        const float w = mw[l * P + p];
         float gx = 0.f, gy = 0.f, gw = 0.f;
-        int64_t o[4] = {-1, -1, -1, -1};        // global line offsets (channel 0) of my corners
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (live && y > -1.f && x > -1.f && y < Hl && x < Wl) {   // uniform over a half-wave
+        if (y > -1.f && x > -1.f && y < Hl && x < Wl) {     // uniform over the item's 8 lanes
           const Corner c = corners(x, y, Hl, Wl, base, row_stride);
-          const float d00 = ld1(vb, c.o00) * go, d01 = ld1(vb, c.o01) * go,
-                      d10 = ld1(vb, c.o10) * go, d11 = ld1(vb, c.o11) * go;
+          const float4 v00 = ld4(vb, c.o00), v01 = ld4(vb, c.o01), v10 = ld4(vb, c.o10),
+                       v11 = ld4(vb, c.o11);
+          const float d00 = v00.x * go.x + v00.y * go.y + v00.z * go.z + v00.w * go.w;
+          const float d01 = v01.x * go.x + v01.y * go.y + v01.z * go.z + v01.w * go.w;
+          const float d10 = v10.x * go.x + v10.y * go.y + v10.z * go.z + v10.w * go.w;
+          const float d11 = v11.x * go.x + v11.y * go.y + v11.z * go.z + v11.w * go.w;
           const float hh = 1.f - c.lh, hw = 1.f - c.lw;
           gw = c.w00 * d00 + c.w01 * d01 + c.w10 * d10 + c.w11 * d11;
           gx = w * Wl * (-hh * d00 + hh * d01 - c.lh * d10 + c.lh * d11);
           gy = w * Hl * (-hw * d00 - c.lw * d01 + hw * d10 + c.lw * d11);
-          const float wg = w * go;
-          if (c.o00 >= 0) { o[0] = gbase + c.o00; v[0] = c.w00 * wg; }
-          if (c.o01 >= 0) { o[1] = gbase + c.o01; v[1] = c.w01 * wg; }
-          if (c.o10 >= 0) { o[2] = gbase + c.o10; v[2] = c.w10 * wg; }
-          if (c.o11 >= 0) { o[3] = gbase + c.o11; v[3] = c.w11 * wg; }
-        }
-        // exchange with the partner half (same channel, other query)
-        int64_t po[4];
-        float pv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          po[j] = __shfl_xor((long long)o[j], kBLanes, 64);
-          pv[j] = __shfl_xor(v[j], kBLanes, 64);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float total = v[i];
-          bool issue = o[i] >= 0;
-          if (half == 0) {                      // owner of shared lines: add the partner's share
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (issue && po[j] == o[i]) total += pv[j];
-          } else {                              // a line the lower half also writes is left to it
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (po[j] >= 0 && po[j] == o[i]) issue = false;
-          }
-          if (issue) unsafeAtomicAdd(gvb + o[i], total);
+        for (int m = 1; m < kLanes; m <<= 1) {
+          gx += __shfl_xor(gx, m, 64); gy += __shfl_xor(gy, m, 64); gw += __shfl_xor(gw, m, 64);
         }
-        gx = half_wave_sum(gx); gy = half_wave_sum(gy); gw = half_wave_sum(gw);
-        if (ch == 0 && live) {
+        // all 8 lanes of the item read (x, y, w) of this point before the shuffles finished
+        if (sub == 0) {
           ml[(l * P + p) * 2] = gx;
           ml[(l * P + p) * 2 + 1] = gy;
           mw[l * P + p] = gw;
@@ -318,16 +495,33 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_pair_kernel(
     }
   }
   __syncthreads();
-  for (int half = 0; half < nhalf; ++half) {
-    const int64_t item_first = (bq0 + half) * H + h0;
-    const float* sl = s_loc + half * kPHeads * LP * 2;
-    const float* sw = s_w + half * kPHeads * LP;
-    for (int i = threadIdx.x; i < nh * LP * 2; i += kThreads) grad_loc[item_first * LP * 2 + i] = sl[i];
-    for (int i = threadIdx.x; i < nh * LP; i += kThreads) grad_w[item_first * LP + i] = sw[i];
-  }
+  for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) grad_loc[item0 * LP * 2 + i] = s_loc[i];
+  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) grad_w[item0 * LP + i] = s_w[i];
 }
 
-int g_bwd_pair_merge = 0;
+// workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks: 4]
+// [chunk table: 4 * max_chunks][records: n_samples].  The level shapes live on the device, so the host
+// sizes the tables from a bound: a level of h x w pixels has (h/8+1)(w/8+1) <= 9hw/64 + 2 tiles.
+struct BinPlan {
+  int64_t n_samples, nbins_bound, max_chunks, tiles_bound;
+  size_t off_chunks, off_desc, off_rec, bytes;
+  bool ok;
+};
+inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
+  BinPlan p{};
+  p.n_samples = (int64_t)B * Nq * H * L * P;
+  p.tiles_bound = ((int64_t)Nv * 9) / 64 + 2 * L + 1;
+  p.nbins_bound = (int64_t)B * H * p.tiles_bound;
+  p.max_chunks = p.n_samples / kChunk + p.nbins_bound;
+  p.off_chunks = sizeof(int) * (size_t)p.nbins_bound;
+  p.off_desc = p.off_chunks + 16;
+  p.off_rec = p.off_desc + 16 * (size_t)p.max_chunks;
+  p.bytes = p.off_rec + sizeof(int) * (size_t)p.n_samples;
+  p.ok = L <= kMaxL && p.n_samples > 0 && p.n_samples < (1ll << 31) &&
+         (int64_t)B * Nq * H * kCh < (1ll << 31) && p.nbins_bound < (1ll << 28) &&
+         p.tiles_bound <= kMaxTilesLds && (int64_t)B * H * L < 65536;
+  return p;
+}
 
 inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
   return B < 0 || Nv < 0 || H <= 0 || C != kCh || Nq < 0 || L <= 0 || P <= 0 || L * P > kMaxLP;
@@ -336,17 +530,6 @@ inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
 }  // namespace
 
 extern "C" {
-
-int vidar_msda_set_xcd_remap(int enabled) {
-  const int v = enabled ? 0 : 1;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_no_remap), &v, sizeof(int));
-}
-
-int vidar_msda_set_bwd_pair_merge(int enabled) {
-  const int prev = g_bwd_pair_merge;
-  g_bwd_pair_merge = enabled ? 1 : 0;
-  return prev;
-}
 
 int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
@@ -365,11 +548,17 @@ int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
   return vidar_last_error();
 }
 
+size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P) {
+  if (B <= 0 || Nv <= 0 || H <= 0 || Nq <= 0 || L <= 0 || P <= 0) return 0;
+  const BinPlan p = bin_plan(B, Nv, H, Nq, L, P);
+  return p.ok ? p.bytes : 0;
+}
+
 int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, const float* grad_out, float* grad_value,
                        float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
-                       int Nq, int L, int P, void* stream) {
+                       int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
   if (msda_bad(B, Nv, H, C, Nq, L, P)) return VIDAR_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -380,15 +569,36 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
   }
   const int64_t n_items = (int64_t)B * Nq * H;
   if (n_items == 0) return 0;
-  if (g_bwd_pair_merge) {
-    const int64_t n_bq = (int64_t)B * Nq;
-    const int n_hg = (H + kPHeads - 1) / kPHeads;
-    const int nb = (int)(((n_bq + 1) / 2) * n_hg);
-    const int grid_p = ((nb + 7) / 8) * 8;
-    const size_t lds_p = sizeof(float) * kPItems * L * P * 3;
-    hipLaunchKernelGGL(msda_bwd_pair_kernel, dim3(grid_p), dim3(kThreads), lds_p, s, value, spatial_shapes,
-                       level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
-                       grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_bq, n_hg, nb);
+  if (workspace) {
+    // destination-binned scatter + gather for grad_loc / grad_w
+    if (Nv == 0) return VIDAR_ERR_BAD_ARG;
+    const BinPlan p = bin_plan(B, Nv, H, Nq, L, P);
+    if (!p.ok || workspace_bytes < p.bytes) return VIDAR_ERR_BAD_ARG;
+    char* ws = (char*)workspace;
+    int* counts = (int*)ws;
+    int* n_chunks = (int*)(ws + p.off_chunks);
+    int4* desc = (int4*)(ws + p.off_desc);
+    int* rec = (int*)(ws + p.off_rec);
+    hipError_t e = hipMemsetAsync(counts, 0, p.off_desc, s);
+    if (e != hipSuccess) return (int)e;
+    const dim3 bgrid((Nq + kBinQ - 1) / kBinQ, B * H * L);
+    const size_t blds = sizeof(int) * (size_t)p.tiles_bound;
+    hipLaunchKernelGGL(msda_bin_kernel<false>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
+                       counts, rec, H, Nq, L, P);
+    hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, spatial_shapes, counts, desc,
+                       n_chunks, B, H, L);
+    hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), 2 * blds, s, spatial_shapes, sampling_loc,
+                       counts, rec, H, Nq, L, P);
+    const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
+    hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
+                       Nv, H, L, P);
+    const int nblocks = (int)((n_items + kItems - 1) / kItems);
+    const int grid = ((nblocks + 7) / 8) * 8;
+    const size_t lds = sizeof(float) * kItems * L * P * 3;
+    hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
+                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks);
     return vidar_last_error();
   }
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);

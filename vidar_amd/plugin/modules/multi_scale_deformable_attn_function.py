@@ -32,16 +32,39 @@ def _msda_forward(value, shapes, lsi, loc, w):
     return out
 
 
-def _msda_backward(value, shapes, lsi, loc, w, grad_out):
+# launches with at least this many (b, q, head, level, point) samples take the destination-binned
+# scatter (5 launches, no atomic wall); smaller ones the one-launch atomic scatter.  Same results up to
+# fp32 summation order; tests/test_msda_gpu.py runs every case under both.
+BINNED_MIN_SAMPLES = 1 << 18
+
+
+def _bwd_workspace(value, B, Nv, H, Nq, L, P, binned):
+    import ctypes
+    if binned is None:
+        binned = B * Nq * H * L * P >= BINNED_MIN_SAMPLES
+    if not binned:
+        return None, 0
+    f = lib().vidar_msda_bwd_workspace_bytes
+    f.restype = ctypes.c_size_t
+    n = int(f(B, Nv, H, Nq, L, P))
+    if n == 0:
+        return None, 0
+    return torch.empty((n + 7) // 8, dtype=torch.int64, device=value.device), n
+
+
+def _msda_backward(value, shapes, lsi, loc, w, grad_out, binned=None):
+    import ctypes
     B, Nv, H, C = value.shape
     _, Nq, _, L, P, _ = loc.shape
     gv = torch.empty_like(value)
     gl = torch.empty_like(loc)
     gw = torch.empty_like(w)
+    ws, nbytes = _bwd_workspace(value, B, Nv, H, Nq, L, P, binned)
     with TIMER.span(f"msda_bwd[L={L},P={P}]", msda_bwd_bytes(B, Nv, H, C, Nq, L, P)):
         check(lib().vidar_msda_bwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w),
                                        ptr(grad_out), ptr(gv), ptr(gl), ptr(gw), B, Nv, H, C, Nq, L, P,
-                                       stream_of(value)), "ms_deform_attn_backward")
+                                       ptr(ws), ctypes.c_size_t(nbytes), stream_of(value)),
+              "ms_deform_attn_backward")
     return gv, gl, gw
 
 
