@@ -29,12 +29,18 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KB -> bytes; FETCH not
-# doubled: the x2 rule of the microarch guide is calibrated for wide coalesced streams only).
-# Source: profiles/r01_pmc_{FETCH,WRITE}_SIZE_kbench_msda_lr.csv (tools/pmc_traffic.sh, SCA shape
-# B=6, Nq=10^4, L=4, P=8 / TSA shape B=2, Nq=4*10^4).  Atomic read-modify-writes show up as writes.
-PMC_TRAFFIC = {"msda_bwd[L=4,P=8]": (1392835.0 + 5508074.1) * 1024,
-               # TSA row = 3*mean - min(Pred) - max(SCA) of the 39 equally split dispatches
-               "msda_bwd[L=1,P=4]": (457348.7 + 920731.2) * 1024}
+# doubled: the x2 rule of the microarch guide is calibrated for wide coalesced streams only).  These
+# are NOT measured by this process: they are read back from the committed PMC summaries of a kbench run
+# at the same shapes and labelled with their source file in the JSON line (`traffic_source`).
+PMC_TRAFFIC = ROOT / "profiles" / "pmc_traffic.json"     # {op name: {"bytes": ..., "source": "profiles/..."}}
+
+
+def pmc_traffic(name):
+    try:
+        rec = json.loads(PMC_TRAFFIC.read_text()).get(name)
+    except (OSError, ValueError):
+        rec = None
+    return (rec["bytes"], rec["source"]) if rec else (None, None)
 
 
 def parse():
@@ -50,8 +56,12 @@ def parse():
                     help="feed FPN pyramids instead of images (hot path of SURVEY 8a only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 16))
-    ap.add_argument("--cpu-baseline-timeout", type=int, default=240)
+    ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 64))
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=600)
+    ap.add_argument("--cpu-baseline-reduced", action="store_true",
+                    help="time the CPU leg at BEV 50x50 / quarter-resolution images instead of full size")
+    ap.add_argument("--no-kernel-rooflines", action="store_true",
+                    help="skip the per-kernel roofline list (dvr family + MSDA at BASELINE shapes)")
     ap.add_argument("--op-table", action="store_true", help="print the per-op timing table to stderr")
     return ap.parse_args()
 
@@ -61,67 +71,153 @@ def synthetic_images(seed, T, num_cams, hw, device, scale=1):
     return torch.randn(1, T, num_cams, 3, hw[0] // scale, hw[1] // scale, generator=g).to(device)
 
 
-def cpu_baseline(config, threads, with_backbone=True):
-    """The oracle port of the same training step on host cores, bounded sample: BEV 50x50 (1/16 of
-    the 40 000 queries), FPN pyramid of a quarter-resolution input, rays_per_frame/16 GT rays."""
+def cpu_baseline(config, threads, with_backbone=True, reduced=False):
+    """The oracle port of the same training step on host cores: ONE full-size step (BEV 200x200, full
+    images, 30 000 rays/frame -- the workload of the GPU line), measured, no extrapolation.  `reduced`
+    (fallback when the full-size step does not fit the time limit) times BEV 50x50 with quarter-resolution
+    images and 1 875 rays/frame and says so."""
     from oracle import cpu_ops
     from vidar_amd import train as T
     from vidar_amd.configs import get_config
     from vidar_amd.synthetic import fpn_features, make_sample
     torch.set_num_threads(threads)
-    cfg = get_config(config, bev_h=50, bev_w=50, with_backbone=with_backbone)
+    div = 4 if reduced else 1
+    cfg = get_config(config, bev_h=200 // div, bev_w=200 // div, with_backbone=with_backbone)
     torch.manual_seed(0); np.random.seed(0)
     model = T.build_model(cfg).train()
     opt = T.build_optimizer(model)
-    metas, gt = make_sample(0, rays_per_frame=30000 // 16, future_frames=cfg["future_frames"],
+    metas, gt = make_sample(0, rays_per_frame=30000 // (div * div), future_frames=cfg["future_frames"],
                             num_cams=cfg["num_cams"], img_hw=cfg["img_hw"])
     if with_backbone:
-        qhw = (cfg["img_hw"][0] // 4, cfg["img_hw"][1] // 4)
+        qhw = (cfg["img_hw"][0] // div, cfg["img_hw"][1] // div)
         for m in metas:
             m["img_shape"] = [(qhw[0], qhw[1], 3)] * cfg["num_cams"]
-            k = np.diag([0.25, 0.25, 1.0, 1.0])
+            k = np.diag([1.0 / div, 1.0 / div, 1.0, 1.0])
             m["lidar2img"] = [k @ a for a in m["lidar2img"]]
         batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt)],
-                     img=synthetic_images(0, 5, cfg["num_cams"], cfg["img_hw"], "cpu", scale=4))
+                     img=synthetic_images(0, 5, cfg["num_cams"], cfg["img_hw"], "cpu", scale=div))
     else:
-        shapes = [((h + 3) // 4, (w + 3) // 4) for h, w in cfg["fpn_shapes"]]
+        shapes = [((h + div - 1) // div, (w + div - 1) // div) for h, w in cfg["fpn_shapes"]]
         feats = fpn_features(0, 5, num_cams=cfg["num_cams"], shapes=shapes)
         batch = dict(img_metas=[metas], gt_points=[torch.from_numpy(gt)], img_feats=feats)
     with cpu_ops.patched():
-        T.train_step(model, opt, batch)             # warm-up
+        if reduced:
+            T.train_step(model, opt, batch)         # warm-up (cheap at this size)
         t0 = time.perf_counter()
-        n = 1
-        for _ in range(n):
-            T.train_step(model, opt, batch)
-        dt = (time.perf_counter() - t0) / n
-    scale = 16.0
-    return dict(value=1.0 / (dt * scale), unit="samples/s", cores=threads, kind="port",
-                sample=f"oracle port of the step ({'with' if with_backbone else 'without'} backbone) at BEV "
-                       f"50x50, 1/4-res images (1/16 of the pixels), 1875 rays/frame: "
-                       f"{dt:.2f} s/step measured, x{scale:.0f} work -> full-size estimate")
+        T.train_step(model, opt, batch)
+        dt = time.perf_counter() - t0
+    what = "with" if with_backbone else "without"
+    if reduced:
+        return dict(value=1.0 / (dt * 16.0), unit="samples/s", cores=threads, kind="port",
+                    sample=f"REDUCED: oracle port of the step ({what} backbone) at BEV 50x50, 1/4-res images, "
+                           f"1875 rays/frame: {dt:.2f} s/step measured, x16 work -> full-size ESTIMATE")
+    return dict(value=1.0 / dt, unit="samples/s", cores=threads, kind="port",
+                sample=f"oracle port of ONE full-size training step ({what} backbone; BEV 200x200, "
+                       f"{cfg['num_cams']}x{cfg['img_hw'][0]}x{cfg['img_hw'][1]} images, 30000 rays/frame, first step, "
+                       f"no warm-up): {dt:.1f} s measured on {threads} torch threads")
 
 
 def cpu_baseline_subprocess(args):
     """Run the CPU leg in a child with a hard wall-clock limit so it can never stall the bench."""
     import subprocess
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--config", args.config,
-           "--cpu-threads", str(args.cpu_threads)] + (["--no-backbone"] if args.no_backbone else [])
+    base = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--config", args.config,
+            "--cpu-threads", str(args.cpu_threads)] + (["--no-backbone"] if args.no_backbone else [])
     env = dict(os.environ, OMP_NUM_THREADS=str(args.cpu_threads), MKL_NUM_THREADS=str(args.cpu_threads))
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_baseline_timeout, env=env)
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        note = "cpu leg produced no result: " + r.stderr.strip()[-200:]
-    except subprocess.TimeoutExpired:
-        note = f"cpu leg exceeded {args.cpu_baseline_timeout} s and was stopped"
+    note = ""
+    # full size first; the reduced sample only if the full-size step does not finish in time
+    for extra, limit in (([], args.cpu_baseline_timeout), (["--cpu-baseline-reduced"], 240)):
+        if args.cpu_baseline_reduced and not extra:
+            continue
+        try:
+            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=limit, env=env)
+            for line in reversed(r.stdout.strip().splitlines()):
+                if line.startswith("{"):
+                    out = json.loads(line)
+                    if note:
+                        out["sample"] += " (" + note + ")"
+                    return out
+            note += "cpu leg produced no result: " + r.stderr.strip()[-200:] + "; "
+        except subprocess.TimeoutExpired:
+            note += f"cpu leg{' (reduced)' if extra else ' (full size)'} exceeded {limit} s and was stopped; "
     return dict(value=None, unit="samples/s", cores=args.cpu_threads, kind="port", sample=note)
+
+
+def hip_time(fn, iters=10, warm=2):
+    """average ms of fn() with HIP events on torch's current stream (the stream every op launches on)."""
+    for _ in range(warm):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_rooflines(dev):
+    """Per-kernel roofline list at the BASELINE shapes, timed live in this process (outside the timed
+    step region): the dvr / dvxlr ray-march family the north star names (30 000 = one frame, 150 000 = a
+    5-frame sample) and the MSDA gather / scatter.  achieved = SURVEY 8d algorithmic bytes / avg ms."""
+    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import (
+        _msda_backward, _msda_forward, msda_bwd_bytes, msda_fwd_bytes)
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvr, dvxlr, dvxlr_v2
+    rows = []
+
+    def add(kernel, ms, nbytes, bound="hbm", note=None):
+        gbps = nbytes / ms / 1e6
+        r = dict(kernel=kernel, avg_ms=round(ms, 4), bytes=int(nbytes), achieved=round(gbps, 1), unit="GB/s",
+                 peak=HBM_PEAK_GBPS, frac=round(gbps / HBM_PEAK_GBPS, 4), bound=bound)
+        if note:
+            r["note"] = note
+        rows.append(r)
+
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for T_, rpf in ((1, 30000), (5, 30000)):
+        sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=T_, rays_per_frame=rpf))
+        N, M = tindex.shape
+        vol = sigma.numel() * 4
+        out = dvxlr.render(sigma, origin, points, tindex)
+        cnt = int(((out[3] != 0).any(-1)).sum())             # traversed voxels (dvr bytes depend on it)
+        add(f"dvxlr.render[M={M}]", hip_time(lambda: dvxlr.render(sigma, origin, points, tindex)),
+            vol + N * M * 16 + N * M * 4 * (2 + 1026 * 4), note="16.4 KB/ray of API-mandated padded rows")
+        em = out[2] * 0.5
+        add(f"dvxlr.get_grad_sigma[M={M}]", hip_time(lambda: dvxlr.get_grad_sigma(em, out[3], tindex, sigma)),
+            N * M * 1026 * 16 + 2 * vol)
+        add(f"dvxlr_v2.render_v2[M={M}]", hip_time(lambda: dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma)),
+            2 * vol + N * M * 16 + N * M * 4 * (2 + 1026 * 6))
+        add(f"dvr.render_forward[M={M}]",
+            hip_time(lambda: dvr.render_forward(sigma, origin, points, tindex, [T_, 16, 200, 200], "train")),
+            vol + N * M * 24 + cnt * 4, bound="fp64 issue (sequential DDA per lane), not HBM")
+        add(f"dvr.render[M={M}]", hip_time(lambda: dvr.render(sigma, origin, points, tindex, "l1")),
+            2 * vol + N * M * 24 + cnt * 12, bound="fp64 issue + per-lane atomics, not HBM")
+        del out, em
+    g = torch.Generator().manual_seed(0)
+    fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
+    for name, B, shapes, Nq, P in (("TSA", 2, [(200, 200)], 40000, 4), ("SCA", 6, fpn, 10000, 8)):
+        L = len(shapes); Nv = sum(h * w for h, w in shapes)
+        value = torch.randn(B, Nv, 8, 32, generator=g).to(dev)
+        ref = torch.rand(B, Nq, 1, 1, 1, 2, generator=g) * 1.2 - 0.1
+        loc = (ref + (torch.rand(B, Nq, 8, L, P, 2, generator=g) * 2 - 1) * 0.05).clamp(-0.1, 1.1).to(dev)
+        w = torch.softmax(torch.randn(B, Nq, 8, L * P, generator=g), -1).view(B, Nq, 8, L, P).to(dev)
+        sh = torch.tensor(shapes, dtype=torch.int64, device=dev)
+        sizes = torch.tensor([h * w for h, w in shapes])
+        lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]]).to(dev)
+        go = torch.randn(B, Nq, 256, generator=g).to(dev)
+        add(f"msda_fwd[{name}]", hip_time(lambda: _msda_forward(value, sh, lsi, loc, w)),
+            msda_fwd_bytes(B, Nv, 8, 32, Nq, L, P), bound="L1/TA line rate (61 M corner lines), reported vs HBM")
+        add(f"msda_bwd[{name}]", hip_time(lambda: _msda_backward(value, sh, lsi, loc, w, go)),
+            msda_bwd_bytes(B, Nv, 8, 32, Nq, L, P))
+    return rows
 
 
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.config, args.cpu_threads, not args.no_backbone)), flush=True)
+        print(json.dumps(cpu_baseline(args.config, args.cpu_threads, not args.no_backbone,
+                                      reduced=args.cpu_baseline_reduced)), flush=True)
         return
     from vidar_amd import train as T
     from vidar_amd._lib import TIMER
@@ -201,10 +297,14 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": PMC_TRAFFIC.get(dom_name),
+                         "traffic": pmc_traffic(dom_name)[0], "traffic_source": pmc_traffic(dom_name)[1],
                          "avg_ms": dom["avg_ms"], "launches_per_step": dom["calls"] / args.steps,
                          "hip_ops_ms_per_step": hip_ms},
         }
+        if world == 1 and not args.no_kernel_rooflines:
+            del batch, ddp, opt, model
+            torch.cuda.empty_cache()
+            out["roofline_kernels"] = kernel_rooflines(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
             out["cpu_baseline"]["host_cores"] = os.cpu_count()

@@ -77,3 +77,24 @@ def test_full_size_properties():
     ones = torch.ones_like(p)
     f = latent_render_gather(p, ones, 256, 1.0, 1e-3)
     assert float(f.max()) <= 1.0 + 1e-5 and float(f.min()) >= 0.0
+
+
+@pytest.mark.parametrize("step", [1.0, 0.5])
+def test_full_size_200x200_matches_oracle(step):
+    """BASELINE BEV (200x200, 256 waypoints, grid_step 1.0 = 1_8 1future / 0.5 = 3future, full, OpenScene):
+    both stages forward + backward against the torch oracle (itself pinned to the reference module)."""
+    from vidar_amd.plugin.modules.ray_operations.latent_rendering import (latent_render_gather,
+                                                                          latent_render_path_prob)
+    gen = torch.Generator().manual_seed(5)
+    occ = torch.randn(1, 200, 200, 16, generator=gen, requires_grad=True)
+    a = torch.randn(1, 200, 200, 16, generator=gen, requires_grad=True)
+    go1 = torch.randn(1, 200, 200, 16, generator=gen); go2 = torch.randn(1, 200, 200, 16, generator=gen)
+    p_ref = LR.path_prob(occ, 256, step, "sigmoid")
+    f_ref = LR.gather(p_ref, a, 256, step)
+    r = torch.autograd.grad((p_ref * go1).sum() + (f_ref * go2).sum(), [occ, a])
+    occ_d = occ.detach().cuda().requires_grad_(True); a_d = a.detach().cuda().requires_grad_(True)
+    p = latent_render_path_prob(occ_d, 256, step, "sigmoid")
+    f = latent_render_gather(p, a_d, 256, step)
+    close(p, p_ref.detach()); close(f, f_ref.detach())
+    d = torch.autograd.grad((p * go1.cuda()).sum() + (f * go2.cuda()).sum(), [occ_d, a_d])
+    close(d[0], r[0], rtol=3e-4, atol=3e-5); close(d[1], r[1], rtol=3e-4, atol=3e-5)

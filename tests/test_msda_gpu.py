@@ -124,10 +124,19 @@ def test_full_size_matches_oracle(name, scatter):
     # of rounding that the fp64 oracle does not have; times |d value / d pixel| ~ 3 (unit-variance value)
     # -> a few 1e-5 absolute on outputs of magnitude ~1 (the fp32 reference kernel has the same rounding)
     torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-4, atol=1e-4)
-    got = F._msda_backward(dv, sh.cuda(), lsi, dl, dw, gout.cuda(), binned=SCATTER[scatter])
+    got = [g.cpu().double() for g in F._msda_backward(dv, sh.cuda(), lsi, dl, dw, gout.cuda(), binned=SCATTER[scatter])]
+    # d/d location of a bilinear sample jumps at pixel boundaries (and at the -1 / size borders): a sample
+    # whose exact pixel coordinate lies within fp32 rounding of an integer may fall into the neighbouring
+    # cell in fp32 (a few of the 5-15 M samples do).  Those samples are excluded from the grad_loc check;
+    # the forward, grad_value and grad_w are continuous there and are compared everywhere.
+    wh = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float64).view(1, 1, 1, len(shapes), 1, 2)
+    pixel = loc.double() * wh - 0.5
+    kink = ((pixel - pixel.round()).abs() < 1e-4).any(-1, keepdim=True).expand_as(loc)
+    assert float(kink.double().mean()) < 1e-3
+    got[1] = torch.where(kink, rl, got[1])
     for g, r, nm in zip(got, (rv, rl, rw), ["grad_value", "grad_loc", "grad_w"]):
         scale = max(1.0, float(r.abs().max()))
-        torch.testing.assert_close(g.cpu().double(), r, rtol=2e-4, atol=1e-4 * scale, msg=lambda m: nm + m)
+        torch.testing.assert_close(g, r, rtol=2e-4, atol=1e-4 * scale, msg=lambda m: nm + m)
 
 
 def test_binned_workspace_contract():

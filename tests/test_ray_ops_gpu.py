@@ -87,3 +87,24 @@ def test_random_volume_16x200x200():
     ce, valid = ray_ce(sigma.cuda(), o.cuda(), p.cuda(), ti.cuda())
     assert torch.equal(valid.cpu() > 0, keep)
     torch.testing.assert_close(ce.cpu()[keep], H.ce_per_ray(feat[keep]), rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_30k_rays_ce_forward_backward():
+    """BASELINE frame: 30 000 GT rays through a 16x200x200 logit volume: kept-ray set, per-ray CE and
+    d loss / d sigma against the oracle (trilinear grid_sample + logsumexp over 513 samples)."""
+    from vidar_amd.plugin.dense_heads.ray_ops import ray_ce
+    from vidar_amd.synthetic import ray_set
+    sig, origin, points, tindex = ray_set(seed=33, N=1, T=1, rays_per_frame=30000)
+    sigma = torch.randn(1, 16, 200, 200, generator=torch.Generator().manual_seed(2))
+    o, p, ti = torch.from_numpy(origin[0]), torch.from_numpy(points[0]), torch.from_numpy(tindex[0])
+    s2 = sigma.clone().requires_grad_(True)
+    feat, length, keep = H.grid_features(s2, o, torch.nan_to_num(p, nan=-1e4), ti)
+    ce_ref = H.ce_per_ray(feat[keep])
+    wts = torch.rand(int(keep.sum()), generator=torch.Generator().manual_seed(3))
+    g_ref, = torch.autograd.grad((ce_ref * wts).sum(), s2)
+    sg = sigma.cuda().requires_grad_(True)
+    ce, valid = ray_ce(sg, o.cuda(), p.cuda(), ti.cuda())
+    assert torch.equal(valid.cpu() > 0, keep)
+    torch.testing.assert_close(ce.detach().cpu()[keep], ce_ref.detach(), rtol=1e-4, atol=1e-4)
+    g, = torch.autograd.grad((ce[keep.cuda()] * wts.cuda()).sum(), sg)
+    torch.testing.assert_close(g.cpu(), g_ref, rtol=3e-4, atol=3e-5 * float(g_ref.abs().max()))

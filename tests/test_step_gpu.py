@@ -15,13 +15,30 @@ def _to(batch, dev):
                 img_feats=[f.to(dev) for f in batch["img_feats"]])
 
 
-@pytest.mark.parametrize("name", ["vidar_1_8_nusc_1future", "vidar_1_8_nusc_3future"])
-def test_hip_step_matches_cpu_oracle_step(name):
+def _batch_of(name, bs):
+    """bs samples of the small rig (bs = 1: test_plugin_cpu._small_batch)."""
+    from vidar_amd.configs import get_config
+    from vidar_amd.synthetic import fpn_features, make_sample
+    if bs == 1:
+        return _small_batch(name)
+    cfg = get_config(name, bev_h=24, bev_w=24)
+    ms, gts = [], []
+    for s_ in range(bs):
+        m, g = make_sample(s_, rays_per_frame=200, future_frames=cfg["future_frames"], num_cams=cfg["num_cams"])
+        ms.append(m); gts.append(torch.from_numpy(g))
+    feats = fpn_features(0, 5, num_cams=cfg["num_cams"], shapes=[(15, 25), (8, 13), (4, 7), (2, 4)], bs=bs)
+    return cfg, dict(img_metas=ms, gt_points=gts, img_feats=feats)
+
+
+@pytest.mark.parametrize("name,bs", [("vidar_1_8_nusc_1future", 1), ("vidar_1_8_nusc_3future", 1),
+                                     ("vidar_OpenScene_mini_full_3future", 1),      # 8 cameras (BASELINE config 4)
+                                     ("vidar_1_8_nusc_1future", 2)])                # per-GPU batch 2 (BASELINE config 3)
+def test_hip_step_matches_cpu_oracle_step(name, bs):
     from oracle import cpu_ops
     from vidar_amd import train as T
     from vidar_amd.plugin.dense_heads import ray_ops
     torch.manual_seed(0); np.random.seed(0)
-    cfg, batch = _small_batch(name)
+    cfg, batch = _batch_of(name, bs)
     model = T.build_model(cfg).eval()          # eval: dropout off, identical control flow
     for m in model.modules():
         if hasattr(m, "random_drop_prev_rate"):
