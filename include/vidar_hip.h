@@ -157,6 +157,20 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * BEV-encoder bookkeeping for F frames at once.  Replaces BEVFormerEncoder.point_sampling
+ * (projects/mmdet3d_plugin/bevformer/modules/encoder.py:96-156) and the visible-query rebatch index of
+ * SpatialCrossAttention.forward (spatial_cross_attention.py:136-152, :164-171).
+ *   ref_3d [D,Q,3] f32 pillar anchors in [0,1] (encoder.py:54-80), lidar2img [F,B,N,4,4] f32 row-major,
+ *   pc_range: HOST pointer to 6 floats, img_h/img_w: padded image shape of camera 0 (encoder.py:137-138).
+ * Outputs (caller-allocated, fully written): ref_cam [F,N,B,Q,D,2] f32, bev_mask [F,N,B,Q,D] u8 (0/1),
+ *   count [F,B,Q] f32 = max(1, #cameras seeing the query), idx [F,N,Q] i64 = visible queries of batch item 0
+ *   in ascending order then zeros, valid [F,N,Q] u8 = slot < lens, lens [F,N] i32.
+ * ------------------------------------------------------------------------- */
+int vidar_sca_plan_f32(const float* ref_3d, const float* lidar2img, float* ref_cam, uint8_t* bev_mask,
+                       float* count, int64_t* idx, uint8_t* valid, int32_t* lens, const float* pc_range,
+                       float img_h, float img_w, int F, int B, int N, int Q, int D, void* stream);
+
+/* ---------------------------------------------------------------------------
  * LatentRendering ray-march (fused).  Replaces the torch op chain of
  * projects/mmdet3d_plugin/bevformer/modules/ray_operations/latent_rendering.py:96-150.
  * All maps are channel-last [bs, H*W, Z] f32 with Z == 16 (pred_height == embed_dims/reduction).

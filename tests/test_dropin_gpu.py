@@ -67,15 +67,15 @@ def test_voxel_rendering_layers_on_hip_match_reference_golden(names):
     p, g = Layer.apply(s, origin, points, tindex)
     (p * c("l1_w")).sum().backward()
     np.testing.assert_allclose(p.detach().cpu().numpy(), gold["l1_pred"], rtol=2e-5, atol=1e-4)
-    np.testing.assert_array_equal(g.cpu().numpy(), gold["l1_gt"])
+    np.testing.assert_array_equal(g.detach().cpu().numpy(), gold["l1_gt"])
     np.testing.assert_allclose(s.grad.cpu().numpy(), gold["l1_grad"], rtol=1e-4, atol=1e-5 * np.abs(gold["l1_grad"]).max())
     s2 = sigma.clone().requires_grad_(True)
     reg = c("l2_reg").clone().requires_grad_(True)
     p2, g2, rp, ind = LayerV2.apply(s2, origin, points, tindex, reg)
-    ((p2 * c("l1_w")).sum() + (rp * c("l2_wr") * (ind >= 0)).sum()).backward()
+    ((p2 * c("l1_w")).sum() + (rp * c("l2_wr") * (ind.detach() >= 0)).sum()).backward()
     np.testing.assert_allclose(p2.detach().cpu().numpy(), gold["l2_pred"], rtol=2e-5, atol=1e-4)
     np.testing.assert_array_equal(rp.detach().cpu().numpy(), gold["l2_ray_pred"])
-    np.testing.assert_array_equal(ind.cpu().numpy(), gold["l2_indicator"])
+    np.testing.assert_array_equal(ind.detach().cpu().numpy(), gold["l2_indicator"])
     np.testing.assert_allclose(s2.grad.cpu().numpy(), gold["l2_grad"], rtol=1e-4, atol=1e-5 * np.abs(gold["l2_grad"]).max())
     np.testing.assert_allclose(reg.grad.cpu().numpy(), gold["l2_grad_reg"], rtol=1e-5, atol=1e-6)
 

@@ -95,6 +95,8 @@ def test_full_size_200x200_matches_oracle(step):
     occ_d = occ.detach().cuda().requires_grad_(True); a_d = a.detach().cuda().requires_grad_(True)
     p = latent_render_path_prob(occ_d, 256, step, "sigmoid")
     f = latent_render_gather(p, a_d, 256, step)
-    close(p, p_ref.detach()); close(f, f_ref.detach())
+    # up to 257-term fp32 products / sums in a different order than the reference's sequential cumprod:
+    # a handful of the 640 000 outputs differ by a few 1e-5 absolute
+    close(p, p_ref.detach(), rtol=3e-4, atol=5e-5); close(f, f_ref.detach(), rtol=3e-4, atol=5e-5)
     d = torch.autograd.grad((p * go1.cuda()).sum() + (f * go2.cuda()).sum(), [occ_d, a_d])
-    close(d[0], r[0], rtol=3e-4, atol=3e-5); close(d[1], r[1], rtol=3e-4, atol=3e-5)
+    close(d[0], r[0], rtol=5e-4, atol=5e-5); close(d[1], r[1], rtol=5e-4, atol=5e-5)

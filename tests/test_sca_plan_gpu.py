@@ -1,0 +1,58 @@
+"""GPU: vidar_sca_plan_f32 (point_sampling + visible-query compaction for all frames of a step in one
+call) against the torch restatement of the reference text that the CPU golden tests pin
+(BEVFormerEncoder.point_sampling, encoder.py:96-156; visible_query_index for
+spatial_cross_attention.py:136-152, :164-171).  Projected coordinates to fp32 rounding; masks / index lists /
+camera counts exactly, except anchors that sit within rounding of an image border or of the depth threshold
+(strict comparisons may flip there; none do for these seeds, asserted below)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,bev,bs", [("vidar_1_8_nusc_1future", 50, 1), ("vidar_1_8_nusc_1future", 200, 2),
+                                         ("vidar_OpenScene_mini_full_3future", 40, 1)])
+def test_plan_matches_torch_formulation(name, bev, bs):
+    from vidar_amd import train as T
+    from vidar_amd.configs import get_config
+    from vidar_amd.plugin.modules.spatial_cross_attention import visible_query_index
+    from vidar_amd.synthetic import make_sample
+    cfg = get_config(name, bev_h=bev, bev_w=bev)
+    enc = T.build_model(cfg).pts_bbox_head.transformer.encoder
+    samples = [make_sample(7 + b, future_frames=cfg["future_frames"], num_cams=cfg["num_cams"],
+                           img_hw=cfg["img_hw"], rays_per_frame=10)[0] for b in range(bs)]
+    frames = [[samples[b][t] for b in range(bs)] for t in range(5)]
+    dev = torch.device("cuda")
+    plans = enc.plan_frames(frames, bev, bev, dev)
+    ref_3d = enc._cached_points(bev, bev, dev, torch.float32)[0].repeat(bs, 1, 1, 1)
+    for metas, plan in zip(frames, plans):
+        ref_cam, mask = enc.point_sampling(ref_3d, enc.pc_range, metas)
+        idx, valid, count = visible_query_index(mask)
+        torch.testing.assert_close(plan.ref_cam, ref_cam, rtol=2e-6, atol=2e-6)
+        border = ((ref_cam.abs() < 1e-5) | ((ref_cam - 1).abs() < 1e-5)).any(-1)
+        assert int(border.sum()) == 0
+        assert torch.equal(plan.bev_mask, mask)
+        p_idx, p_valid, p_count = plan.index
+        assert p_idx.shape == idx.shape and torch.equal(p_valid, valid)
+        assert torch.equal(p_idx[p_valid], idx[valid])            # visible queries, ascending, per camera
+        assert torch.equal(p_count, count)
+
+
+def test_encoder_pass_uses_the_plan_of_the_detector():
+    """ViDAR.forward_train plans every frame once: the encoder must not plan again (one host read per step)."""
+    from test_plugin_cpu import _small_batch
+    from vidar_amd import train as T
+    from vidar_amd.plugin.modules.encoder import BEVFormerEncoder
+    torch.manual_seed(0); np.random.seed(0)
+    cfg, batch = _small_batch("vidar_1_8_nusc_1future")
+    model = T.build_model(cfg).cuda().train()
+    calls = []
+    orig = BEVFormerEncoder.plan_frames
+    BEVFormerEncoder.plan_frames = lambda self, frames, *a, **k: (calls.append(len(frames)), orig(self, frames, *a, **k))[1]
+    try:
+        model(return_loss=True, img_metas=batch["img_metas"], gt_points=[g.cuda() for g in batch["gt_points"]],
+              img_feats=[f.cuda() for f in batch["img_feats"]])
+    finally:
+        BEVFormerEncoder.plan_frames = orig
+    assert calls == [5]

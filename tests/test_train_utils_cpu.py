@@ -63,6 +63,29 @@ def test_fit_loop_logs_and_checkpoints(tmp_path):
     lines = [json.loads(l) for l in open(tmp_path / "log.jsonl")]
     assert [l["iter"] for l in lines] == [1, 2] and "frame.3.regularization.loss.loss" in lines[0]
     assert (tmp_path / "c.pth").exists()
+    # resuming continues the SAME run: global iteration in the log / checkpoint, stops at `iters`
+    from vidar_amd import checkpoint as C
+    model2 = T.build_model(cfg).train(); opt2 = T.build_optimizer(model2)
+    _, it0 = C.resume(model2, opt2, tmp_path / "c.pth")
+    assert it0 == 2
+    with cpu_ops.patched():
+        n = T.fit(model2, opt2, [batch], iters=3, log_every=1, log_path=tmp_path / "log.jsonl",
+                  ckpt_path=tmp_path / "c.pth", ckpt_every=1, start_iter=it0)
+    assert n == 3
+    assert [json.loads(l)["iter"] for l in open(tmp_path / "log.jsonl")] == [1, 2, 3]
+    assert C.resume(T.build_model(cfg), None, tmp_path / "c.pth")[1] == 3
+
+
+def test_state_dict_layout_does_not_depend_on_init_weights():
+    """released checkpoints carry no pts_bbox_head.transformer.reference_points.* (the reference deletes the
+    Linear inside init_weights, vidar_bevformer_head.py:20-23): same layout with or without that call."""
+    from vidar_amd import plugin
+    cfg, _ = _small_batch("vidar_1_8_nusc_1future")
+    a = plugin.build_detector(dict(cfg["model"]))
+    keys = set(a.state_dict())
+    assert not [k for k in keys if "reference_points" in k]
+    a.init_weights()
+    assert set(a.state_dict()) == keys
 
 
 def test_overfitting_one_sample_reduces_the_loss():

@@ -1,23 +1,53 @@
 """Summarise a rocprofv3 results .db (kernel trace): per kernel name -> calls, avg us, total ms.
-    python tools/prof_summary.py gpurun_out/x/prof/run_results.db [substring ...]"""
+    python tools/prof_summary.py RESULTS.db [--steps K] [--csv] [substring ...]
+With --steps K only the dispatches between the first and the last `vidar_marker_kernel` launch (the timed
+region of bench.py) are counted and the columns are per step."""
 import sqlite3
 import sys
 
 
-def main(path, subs):
+def main(argv):
+    path = argv[0]
+    steps, csv_out, subs = 0, False, []
+    it = iter(argv[1:])
+    for a in it:
+        if a == "--steps":
+            steps = int(next(it))
+        elif a == "--csv":
+            csv_out = True
+        else:
+            subs.append(a)
     c = sqlite3.connect(path)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if "kernel_dispatch" in t][0]
     sym = [t for t in tabs if "info_kernel_symbol" in t][0]
-    rows = c.execute(f"select s.display_name, count(*), avg(d.end-d.start), sum(d.end-d.start), min(d.end-d.start), d.grid_size_x "
-                     f"from {kd} d join {sym} s on d.kernel_id=s.id group by s.display_name, d.grid_size_x order by 4 desc")
-    print(f"{'kernel':60s} {'grid':>10s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'total_ms':>10s}")
-    for name, n, avg, tot, mn, grid in rows:
-        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
+    where = ""
+    div = 1.0
+    if steps:
+        marks = [r[0] for r in c.execute(f"select d.start from {kd} d join {sym} s on d.kernel_id=s.id "
+                                         f"where s.display_name like '%vidar_marker_kernel%' order by d.start")]
+        assert len(marks) >= 2, "markers not found"
+        where = f"where d.start > {marks[0]} and d.start < {marks[-1]} and s.display_name not like '%vidar_marker_kernel%'"
+        div = float(steps)
+    rows = list(c.execute(f"select s.display_name, count(*), avg(d.end-d.start), sum(d.end-d.start), min(d.end-d.start) "
+                          f"from {kd} d join {sym} s on d.kernel_id=s.id {where} group by s.display_name order by 4 desc"))
+    total = sum(r[3] for r in rows)
+    ncalls = sum(r[1] for r in rows)
+    if csv_out:
+        print("Name,Calls,TotalMs,AverageUs,MinUs,Percentage")
+    else:
+        print(f"{'kernel':70s} {'calls':>8s} {'avg_us':>10s} {'min_us':>10s} {'total_ms':>10s} {'%':>6s}")
+    for name, n, avg, tot, mn in rows:
         if subs and not any(s in name for s in subs):
             continue
-        print(f"{short:60s} {grid:10d} {n:6d} {avg / 1e3:10.1f} {mn / 1e3:10.1f} {tot / 1e6:10.2f}")
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
+        if csv_out:
+            print(f"\"{short}\",{n / div:.2f},{tot / 1e6 / div:.4f},{avg / 1e3:.2f},{mn / 1e3:.2f},{100.0 * tot / total:.3f}")
+        else:
+            print(f"{short:70s} {n / div:8.1f} {avg / 1e3:10.1f} {mn / 1e3:10.1f} {tot / 1e6 / div:10.2f} {100.0 * tot / total:6.2f}")
+    unit = " per step" if steps else ""
+    print(f"# {ncalls / div:.0f} launches{unit}, {total / 1e6 / div:.2f} ms kernel time{unit}", file=sys.stderr)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2:])
+    main(sys.argv[1:])

@@ -63,9 +63,12 @@ def main():
     ddp = T.wrap_ddp(model, local)
     opt = T.build_optimizer(model, **opt_cfg)
     sched = T.CosineWithWarmup(opt, args.iters)
-    if args.resume_from:
+    it0 = 0
+    if args.resume_from:                 # continue the SAME run: global iteration, schedule position
         _, it0 = C.resume(model, opt, args.resume_from, map_location=dev)
         sched.it = it0
+        if it0 >= args.iters:
+            raise SystemExit(f"checkpoint is at iteration {it0}, --iters {args.iters} leaves nothing to do")
 
     def sample(i):
         metas, gt = make_sample(1000 * rank + i, queue_length=meta["queue_length"],
@@ -84,7 +87,7 @@ def main():
         work.mkdir(parents=True, exist_ok=True)
     n = T.fit(ddp, opt, [sample(i) for i in range(args.samples)], args.iters, scheduler=sched, max_norm=clip,
               log_every=10, log_path=work / "log.jsonl", ckpt_path=work / "latest.pth",
-              ckpt_every=max(1, args.iters // 2), rank=rank)
+              ckpt_every=max(1, args.iters // 2), rank=rank, start_iter=it0)
     if rank == 0:
         print(f"finished {n} iterations; log: {work / 'log.jsonl'}; checkpoint: {work / 'latest.pth'}")
 

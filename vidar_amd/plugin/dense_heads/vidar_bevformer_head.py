@@ -30,12 +30,18 @@ class ViDARBEVFormerHead(nn.Module):
         cw = code_weights if code_weights is not None else [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2]
         self.code_weights = nn.Parameter(torch.tensor(cw), requires_grad=False)
         self.bev_embedding = nn.Embedding(bev_h * bev_w, self.embed_dims)
+        self._drop_reference_points()
+
+    def _drop_reference_points(self):
+        # vidar_bevformer_head.py:20-23 deletes this Linear inside init_weights(); released checkpoints
+        # therefore carry no pts_bbox_head.transformer.reference_points.* keys.  Dropped at construction
+        # too, so the state_dict layout (strict loading) does not depend on init_weights() being called.
+        if hasattr(self.transformer, "reference_points"):
+            del self.transformer.reference_points
 
     def init_weights(self):
         self.transformer.init_weights()
-        if hasattr(self.transformer, "reference_points"):
-            del self.transformer.reference_points      # vidar_bevformer_head.py:20-23: released
-            # checkpoints therefore carry no pts_bbox_head.transformer.reference_points.* keys
+        self._drop_reference_points()
 
     def forward(self, mlvl_feats, img_metas, prev_bev=None, only_bev=False, return_intermediate=False):
         assert only_bev

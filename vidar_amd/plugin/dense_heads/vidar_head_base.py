@@ -205,8 +205,10 @@ class ViDARHeadBase(ViDARHeadTemplate):
                     # get_rendered_pcds keeps rays with a positive rendered distance only (:392-395);
                     # a dense voxel centre that coincides with the origin (zero-length ray) drops out
                     live = d > 0
-                    unit = r / torch.sqrt((r ** 2).sum(1, keepdim=True))
-                    pred = torch.where(live[:, None], unit * d.view(-1, 1), torch.zeros_like(r)) * 0.1
+                    # NaN-free also for the dropped zero-length ray: a masked 0/0 would still poison the
+                    # backward of `unit * d` (0 * NaN), so the norm is floored and d masked BEFORE the product
+                    unit = r / torch.sqrt((r ** 2).sum(1, keepdim=True)).clamp_min(1e-12)
+                    pred = unit * torch.where(live, d, torch.zeros_like(d)).view(-1, 1) * 0.1
                     gt = (gt_grids[b] - o) * 0.1
                     valid = inside & (tindex[b] == f)
                     ls, lt, _, _ = chamfer_distance(pred[None], gt[None], dst_valid=valid[None],

@@ -38,7 +38,15 @@ class ViDAR(nn.Module):
         self.img_neck = NECKS.build(img_neck) if (img_neck and img_neck.get("type") in NECKS) else None
         self.pts_bbox_head = build_head(pts_bbox_head)
         self.future_pred_head = build_head(future_pred_head)
-        self.use_grid_mask = use_grid_mask          # GridMask is host-side image augmentation: not applied
+        # GridMask augmentation (detectors/vidar.py:45-53, :88-92): training only, applied on device
+        from ..utils.grid_mask import GridMask
+        self.use_grid_mask = use_grid_mask
+        self.grid_mask_image = grid_mask_image
+        self.grid_mask_backbone_feat = grid_mask_backbone_feat
+        self.grid_mask_fpn_feat = grid_mask_fpn_feat
+        self.grid_mask_prev = grid_mask_prev
+        self.grid_mask = GridMask(**(grid_mask_cfg or dict(use_h=True, use_w=True, rotate=1, offset=False,
+                                                           ratio=0.5, mode=1, prob=0.7)))
         self.video_test_mode = video_test_mode
         self.backwarded_prev_frame_num = backwarded_prev_frame_num
         self.future_pred_frame_num = future_pred_frame_num
@@ -73,9 +81,15 @@ class ViDAR(nn.Module):
         if img.dim() == 5:
             Bn, N, C, H, W = img.shape
             img = img.reshape(Bn * N, C, H, W)
+        if self.use_grid_mask and self.grid_mask_image:              # vidar.py:139-140
+            img = self.grid_mask(img)
         feats = self.img_backbone(img)
+        if self.use_grid_mask and self.grid_mask_backbone_feat:      # :145-150
+            feats = [self.grid_mask(f) for f in feats]
         if self.img_neck is not None:
             feats = self.img_neck(feats)
+            if self.use_grid_mask and self.grid_mask_fpn_feat:       # :156-161
+                feats = [self.grid_mask(f) for f in feats]
         out = []
         for f in feats:
             BN, C, H, W = f.shape
@@ -151,9 +165,21 @@ class ViDAR(nn.Module):
         return grids[:, -1].contiguous(), aligned, ref2future
 
     # ---- training step (vidar.py:240-387) ----------------------------------------------------------
+    def _plan_sca(self, img_metas, num_frames, device):
+        """camera projection + visible-query index of every frame of the queue in one kernel call and one
+        host read (instead of one of each per encoder pass); the encoder picks the plan up from the metas."""
+        enc = getattr(getattr(self.pts_bbox_head, "transformer", None), "encoder", None)
+        if enc is None or not hasattr(enc, "plan_frames") or device.type != "cuda":
+            return
+        frames = [[m[t] for m in img_metas] for t in range(num_frames)]
+        for metas, plan in zip(frames, enc.plan_frames(frames, self.bev_h, self.bev_w, device)):
+            for m in metas:
+                m["_sca_plan"] = plan
+
     def forward_train(self, points=None, img_metas=None, img=None, gt_points=None, img_feats=None,
                       **kwargs):
         num_frames = img.size(1) if img is not None else img_feats[0].size(1)
+        self._plan_sca(img_metas, num_frames, (img if img is not None else img_feats[0]).device)
         if img is not None and np.random.rand() < self.random_drop_image_rate:
             img[:, -1:, ...] = torch.zeros_like(img[:, -1:, ...])
         if np.random.rand() < self.random_drop_prev_rate:
@@ -164,6 +190,10 @@ class ViDAR(nn.Module):
         prev_img_metas = copy.deepcopy(img_metas)
         prev_bev = self.obtain_history_bev(img, prev_img_metas, img_feats, num_frames - 1,
                                            drop_prev_index=drop_prev_index)
+        if self.grid_mask_prev and prev_bev is not None:             # vidar.py:289-295
+            b, n, c = prev_bev.shape
+            pb = prev_bev.view(b, self.bev_h, self.bev_w, c).permute(0, 3, 1, 2).contiguous()
+            prev_bev = self.grid_mask(pb).view(b, c, n).permute(0, 2, 1).contiguous()
         cur_metas = [m[num_frames - 1] for m in img_metas]
         cur_feats = [f[:, 0] for f in self._queue_feats(img, img_feats, img_metas, num_frames - 1,
                                                         num_frames, grad=True)]
@@ -224,6 +254,7 @@ class ViDAR(nn.Module):
         (utils/eval_utils.py:185-225: l1_error / absrel_error)."""
         self.eval()
         num_frames = img.size(1) if img is not None else img_feats[0].size(1)
+        self._plan_sca(img_metas, num_frames, (img if img is not None else img_feats[0]).device)
         prev_bev = self.obtain_history_bev(img, img_metas, img_feats, num_frames)
         prev_bev = prev_bev[:, None, ...].contiguous()
         n_heads = len(self.future_pred_head.bev_pred_head)

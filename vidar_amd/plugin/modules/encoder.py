@@ -16,6 +16,28 @@ from .ray_operations.latent_rendering import LatentRendering
 from .spatial_cross_attention import visible_query_index
 
 
+class ScaPlan:
+    """What one encoder pass needs about one frame's cameras: the projected pillar anchors, their validity
+    and the visible-query index of SpatialCrossAttention -- built for all frames of a step by one call of
+    vidar_sca_plan_f32 (BEVFormerEncoder.plan_frames) with one host read of the list lengths."""
+    __slots__ = ("ref_cam", "bev_mask", "index")
+
+    def __init__(self, ref_cam, bev_mask, index):
+        self.ref_cam, self.bev_mask, self.index = ref_cam, bev_mask, index
+
+    def __deepcopy__(self, memo):          # img_metas are deep-copied by the detector (vidar.py:286)
+        return self
+
+
+def to_device_async(array, device, dtype=torch.float32):
+    """numpy -> device through pinned memory, no stream synchronisation (a pageable H2D copy blocks the
+    host until the stream has drained)."""
+    t = torch.as_tensor(np.ascontiguousarray(array), dtype=dtype)
+    if device.type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class TransformerLayerSequence(nn.Module):
     def __init__(self, transformerlayers=None, num_layers=None, init_cfg=None):
         super().__init__()
@@ -77,19 +99,65 @@ class BEVFormerEncoder(TransformerLayerSequence):
         mask = torch.nan_to_num(mask)
         return xy.permute(2, 1, 3, 0, 4), mask.permute(2, 1, 3, 0, 4).squeeze(-1)
 
+    def _cached_points(self, bev_h, bev_w, device, dtype):
+        """pillar anchors [1, D, Q, 3] and cell centres [1, Q, 1, 2]: constants of the model, built once"""
+        key = (bev_h, bev_w, str(device), dtype)
+        cache = self.__dict__.setdefault("_ref_cache", {})
+        if key not in cache:
+            cache[key] = (self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2],
+                                                    self.num_points_in_pillar, dim="3d", bs=1, device=device,
+                                                    dtype=dtype),
+                          self.get_reference_points(bev_h, bev_w, dim="2d", bs=1, device=device, dtype=dtype))
+        return cache[key]
+
+    def plan_frames(self, metas_per_frame, bev_h, bev_w, device, dtype=torch.float32):
+        """point_sampling + visible-query index for several frames in ONE kernel call and one host read.
+        metas_per_frame: list over frames of the per-sample img_metas list.  -> list of ScaPlan.
+        (HIP path; on CPU tensors -- the oracle-routed tests -- the torch formulation below is used.)"""
+        if device.type != "cuda":
+            return [None] * len(metas_per_frame)
+        import ctypes
+        from ..._lib import lib, check, ptr, stream_of
+        F, B = len(metas_per_frame), len(metas_per_frame[0])
+        l2i = np.asarray([[m["lidar2img"] for m in metas] for metas in metas_per_frame], dtype=np.float32)
+        N = l2i.shape[2]
+        ref_3d = self._cached_points(bev_h, bev_w, device, dtype)[0].float().contiguous()
+        D, Q = ref_3d.shape[1], ref_3d.shape[2]
+        l2i_d = to_device_async(l2i, device)
+        ref_cam = torch.empty((F, N, B, Q, D, 2), device=device)
+        mask = torch.empty((F, N, B, Q, D), device=device, dtype=torch.uint8)
+        count = torch.empty((F, B, Q), device=device)
+        idx = torch.empty((F, N, Q), device=device, dtype=torch.int64)
+        valid = torch.empty((F, N, Q), device=device, dtype=torch.uint8)
+        lens = torch.empty((F, N), device=device, dtype=torch.int32)
+        shape0 = metas_per_frame[0][0]["img_shape"][0]
+        rng = (ctypes.c_float * 6)(*[float(v) for v in self.pc_range])
+        check(lib().vidar_sca_plan_f32(ptr(ref_3d), ptr(l2i_d), ptr(ref_cam), ptr(mask), ptr(count), ptr(idx),
+                                       ptr(valid), ptr(lens), rng, ctypes.c_float(float(shape0[0])),
+                                       ctypes.c_float(float(shape0[1])), F, B, N, Q, D, stream_of(ref_cam)),
+              "sca_plan")
+        max_len = lens.max(dim=1).values.tolist()            # the one host read of the step
+        return [ScaPlan(ref_cam[f], mask[f].bool(),
+                        (idx[f, :, :max_len[f]], valid[f, :, :max_len[f]].bool(), count[f]))
+                for f in range(F)]
+
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
                 spatial_shapes=None, level_start_index=None, valid_ratios=None, prev_bev=None,
                 shift=0., **kwargs):
         output = bev_query
         intermediate = []
         bs = bev_query.size(1)
-        ref_3d = self.get_reference_points(bev_h, bev_w, self.pc_range[5] - self.pc_range[2],
-                                           self.num_points_in_pillar, dim="3d", bs=bs,
-                                           device=bev_query.device, dtype=bev_query.dtype)
-        ref_2d = self.get_reference_points(bev_h, bev_w, dim="2d", bs=bs, device=bev_query.device,
-                                           dtype=bev_query.dtype)
-        reference_points_cam, bev_mask = self.point_sampling(ref_3d, self.pc_range, kwargs["img_metas"])
-        sca_index = visible_query_index(bev_mask)        # once per pass instead of once per layer
+        ref_3d, ref_2d = self._cached_points(bev_h, bev_w, bev_query.device, bev_query.dtype)
+        ref_3d, ref_2d = ref_3d.repeat(bs, 1, 1, 1), ref_2d.repeat(bs, 1, 1, 1)
+        img_metas = kwargs["img_metas"]
+        plan = img_metas[0].get("_sca_plan")
+        if plan is None:                                  # not planned by the detector: plan this frame alone
+            plan = self.plan_frames([img_metas], bev_h, bev_w, bev_query.device, bev_query.dtype)[0]
+        if plan is not None:
+            reference_points_cam, bev_mask, sca_index = plan.ref_cam, plan.bev_mask, plan.index
+        else:                                             # CPU tensors (oracle-routed tests)
+            reference_points_cam, bev_mask = self.point_sampling(ref_3d, self.pc_range, img_metas)
+            sca_index = visible_query_index(bev_mask)    # once per pass instead of once per layer
         shift_ref_2d = ref_2d.clone() + shift[:, None, None, :]
         bev_query = bev_query.permute(1, 0, 2)
         bev_pos = bev_pos.permute(1, 0, 2)

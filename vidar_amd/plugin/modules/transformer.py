@@ -53,7 +53,8 @@ class PerceptionTransformer(nn.Module):
                 m.init_weights()
         nn.init.normal_(self.level_embeds)
         nn.init.normal_(self.cams_embeds)
-        xavier_init(self.reference_points, distribution="uniform", bias=0.)
+        if hasattr(self, "reference_points"):         # ViDARBEVFormerHead drops it (vidar_bevformer_head.py:20-23)
+            xavier_init(self.reference_points, distribution="uniform", bias=0.)
         xavier_init(self.can_bus_mlp, distribution="uniform", bias=0.)
 
     def get_bev_features(self, mlvl_feats, bev_queries, bev_h, bev_w, grid_length=[0.512, 0.512],

@@ -130,14 +130,14 @@ class CosineWithWarmup:
 
 
 def fit(model, optimizer, batches, iters, scheduler=None, max_norm=35.0, log_every=50, log_path=None,
-        ckpt_path=None, ckpt_every=0, rank=0):
+        ckpt_path=None, ckpt_every=0, rank=0, start_iter=0):
     """Thin training loop (the reference delegates this to mmcv's EpochBasedRunner + hooks, which are
     out of scope): `batches` is any iterable of forward_train kwargs; JSON-lines log of the loss
     terms and samples/s; optional periodic checkpoints in the mmcv dictionary layout."""
     import json
     import time
     from .checkpoint import save_checkpoint
-    it = 0
+    it = start_iter          # global iteration: a resumed run continues counting (and stops at `iters`)
     t0 = time.perf_counter()
     log = open(log_path, "a") if (log_path and rank == 0) else None
     while it < iters:
@@ -148,7 +148,7 @@ def fit(model, optimizer, batches, iters, scheduler=None, max_norm=35.0, log_eve
             it += 1
             if log is not None and (it % log_every == 0 or it == iters):
                 rec = dict(iter=it, lr=optimizer.param_groups[0]["lr"], loss=float(total),
-                           samples_per_s_per_rank=it / (time.perf_counter() - t0),
+                           samples_per_s_per_rank=(it - start_iter) / (time.perf_counter() - t0),
                            **{k: float(v) for k, v in parts.items()})
                 log.write(json.dumps(rec) + "\n"); log.flush()
             if ckpt_path and ckpt_every and it % ckpt_every == 0 and rank == 0:
