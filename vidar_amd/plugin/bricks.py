@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -107,12 +109,15 @@ def rotate_nearest(img, angle_deg, center):
     m = [c, s, 0.0, -s, c, 0.0]
     m[2] += m[0] * (-cx) + m[1] * (-cy) + cx
     m[5] += m[3] * (-cx) + m[4] * (-cy) + cy
-    theta = img.new_tensor(m, dtype=torch.float32).view(2, 3)
+    from .utils.host import to_device_async
+    # the 2x3 inverse affine already divided by the half extents (host math; one tiny pinned H2D copy)
+    scaled = (np.asarray(m, dtype=np.float32).reshape(2, 3).T / np.asarray([0.5 * W, 0.5 * H], dtype=np.float32))
+    theta_t = to_device_async(scaled, img.device)
     xs = torch.linspace(-W * 0.5 + 0.5, W * 0.5 - 0.5, W, device=img.device)
     ys = torch.linspace(-H * 0.5 + 0.5, H * 0.5 - 0.5, H, device=img.device)
     gy, gx = torch.meshgrid(ys, xs, indexing="ij")
     base = torch.stack((gx, gy, torch.ones_like(gx)), -1).view(-1, 3)
-    grid = base @ (theta.t() / theta.new_tensor([0.5 * W, 0.5 * H]))
+    grid = base @ theta_t
     out = F.grid_sample(img.float().unsqueeze(0), grid.view(1, H, W, 2), mode="nearest",
                         padding_mode="zeros", align_corners=False)
     return out[0].to(img.dtype)

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import numpy as np
 import torch
+
+from ..utils.host import const_tensor, to_device_async
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -156,7 +158,7 @@ class ViDARHeadBase(ViDARHeadTemplate):
         interval = 4
         v = e2e_predictor_utils.get_bev_grids_3d(H // interval, W // interval, Z // interval, bs=1,
                                                  device=device)
-        v = (v * v.new_tensor([W, H, Z])).view(-1, 3)
+        v = (v * const_tensor([W, H, Z], v.device, v.dtype)).view(-1, 3)
         pts = v.repeat(F_, 1)
         tix = torch.arange(F_, device=device, dtype=v.dtype).repeat_interleave(v.shape[0])
         return pts, tix, v.shape[0]
@@ -171,7 +173,7 @@ class ViDARHeadBase(ViDARHeadTemplate):
             bev_preds, gt_points, batched_origin_points, valid_frames, start_idx, pred_frame_num,
             H, W, tgt_pc_range)
         loss_weight = self.loss_weight if loss_weight is None else loss_weight
-        lw = torch.as_tensor(np.asarray(loss_weight, dtype=np.float32)[:, 0], device=bev_preds.device)
+        lw = const_tensor(np.asarray(loss_weight, dtype=np.float32)[:, 0], bev_preds.device)
         step = self.ray_grid_step
         loss_dict = dict()
         sigmas = [self._volumes(bev_preds, b, Z, H, W) for b in range(bs)]
@@ -190,7 +192,7 @@ class ViDARHeadBase(ViDARHeadTemplate):
         if self.use_dense_loss:
             pts, tix, per_frame = self._dense_rays(bs, F_, Z, H, W, bev_preds.device)
             total = bev_preds.new_zeros(())
-            size = gt_grids.new_tensor([W - 1, H - 1, Z - 1])
+            size = const_tensor([W - 1, H - 1, Z - 1], gt_grids.device, gt_grids.dtype)
             for b in range(bs):
                 noise = (self.gumbel_noise_fn(pts.shape[0], self.ray_grid_num) if self.gumbel_noise_fn
                          else ray_ops.gumbel_noise(pts.shape[0], self.ray_grid_num, pts.device))

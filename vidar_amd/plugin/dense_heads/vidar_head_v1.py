@@ -6,6 +6,8 @@ import copy
 
 import numpy as np
 import torch
+
+from ..utils.host import const_tensor, to_device_async
 import torch.nn as nn
 
 from ..registry import HEADS
@@ -55,14 +57,14 @@ class ViDARHeadV1(ViDARHeadBase):
         for s, t in zip(src_frame_idx_list, tgt_frame_idx_list):
             a = np.array([m["total_cur2ref_lidar_transform"][s] for m in img_metas])
             b = np.array([m["total_ref2cur_lidar_transform"][t] for m in img_metas])
-            src_to_tgt.append(torch.matmul(torch.as_tensor(a, dtype=dt, device=dev),
-                                           torch.as_tensor(b, dtype=dt, device=dev)))
+            src_to_tgt.append(torch.matmul(to_device_async(a, dev, dt), to_device_async(b, dev, dt)))
         src_to_tgt = torch.stack(src_to_tgt, 1)                       # [bs, F, 4, 4] row-vector form
         origin = src_to_tgt[:, :, 3, :3].contiguous()                 # (0,0,0,1) @ M
         n_src = int(max(src_frame_idx_list)) + 2
-        slot_of = torch.full((n_src + 1,), -1.0, device=dev, dtype=dt)
+        slot_host = np.full((n_src + 1,), -1.0, dtype=np.float32)
         for f, s in enumerate(src_frame_idx_list):
-            slot_of[int(s)] = f
+            slot_host[int(s)] = f
+        slot_of = const_tensor(slot_host, dev, dt)
         out = []
         for b, p in enumerate(gt_points):
             frame = torch.nan_to_num(p[:, -1], nan=-1.0).long().clamp(min=-1, max=n_src - 1)

@@ -13,6 +13,8 @@ import os
 
 import numpy as np
 import torch
+
+from ..utils.host import to_device_async
 import torch.nn as nn
 
 from ..registry import BACKBONES, DETECTORS, NECKS, build_head
@@ -146,13 +148,13 @@ class ViDAR(nn.Module):
     # ---- future alignment (vidar.py:175-237) -------------------------------------------------------
     def _get_history_ref_to_previous_transform(self, tensor, num_frames, img_metas_list):
         mats = [[m[i]["ref_lidar_to_cur_lidar"] for i in range(num_frames)] for m in img_metas_list]
-        return tensor.new_tensor(np.array(mats))
+        return to_device_async(np.array(mats), tensor.device, tensor.dtype)
 
     def _align_bev_coordnates(self, frame_idx, ref_to_history_list, img_metas):
         bs, num_frame = ref_to_history_list.shape[:2]
         t = ref_to_history_list
-        future2ref = t.new_tensor(np.array([m["future2ref_lidar_transform"][frame_idx] for m in img_metas]))
-        ref2future = t.new_tensor(np.array([m["ref2future_lidar_transform"][frame_idx] for m in img_metas]))
+        future2ref = to_device_async(np.array([m["future2ref_lidar_transform"][frame_idx] for m in img_metas]), t.device, t.dtype)
+        ref2future = to_device_async(np.array([m["ref2future_lidar_transform"][frame_idx] for m in img_metas]), t.device, t.dtype)
         future_to_history = torch.matmul(future2ref.unsqueeze(1).repeat(1, num_frame, 1, 1), t)
         grids = e2e_predictor_utils.get_bev_grids(self.bev_h, self.bev_w, bs * num_frame, device=t.device)
         grids = grids.view(bs, num_frame, -1, 2)

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ..utils.host import const_tensor, to_device_async
 from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_transformer_layer
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 from .ray_operations.latent_rendering import LatentRendering
@@ -27,15 +28,6 @@ class ScaPlan:
 
     def __deepcopy__(self, memo):          # img_metas are deep-copied by the detector (vidar.py:286)
         return self
-
-
-def to_device_async(array, device, dtype=torch.float32):
-    """numpy -> device through pinned memory, no stream synchronisation (a pageable H2D copy blocks the
-    host until the stream has drained)."""
-    t = torch.as_tensor(np.ascontiguousarray(array), dtype=dtype)
-    if device.type != "cuda":
-        return t.to(device)
-    return t.pin_memory().to(device, non_blocking=True)
 
 
 class TransformerLayerSequence(nn.Module):
@@ -225,8 +217,8 @@ class BEVFormerLayerV2(MyCustomBaseTransformerLayer):
                 spatial_shapes=None, level_start_index=None, prev_bev=None, **kwargs):
         norm_index = attn_index = ffn_index = 0
         identity = query
-        self_shapes = torch.tensor([[bev_h, bev_w]], device=query.device)
-        self_lsi = torch.tensor([0], device=query.device)
+        self_shapes = const_tensor([[bev_h, bev_w]], query.device, torch.int64)
+        self_lsi = const_tensor([0], query.device, torch.int64)
         for layer in self.operation_order:
             if layer == "self_attn":
                 query = self.attentions[attn_index](

@@ -67,8 +67,8 @@ class SpatialCrossAttention(nn.Module):
         vmask = valid[None, :, :, None].to(query.dtype)
         # [bs, cams, max_len, C] / [bs, cams, max_len, D, 2]; padded slots are zero like the reference
         q_re = query[:, idx] * vmask
-        ref_re = reference_points_cam.permute(1, 0, 2, 3, 4)[torch.arange(bs)[:, None, None],
-                                                                torch.arange(self.num_cams)[None, :, None],
+        ref_re = reference_points_cam.permute(1, 0, 2, 3, 4)[torch.arange(bs, device=idx.device)[:, None, None],
+                                                                torch.arange(self.num_cams, device=idx.device)[None, :, None],
                                                                 idx[None]] * vmask[..., None]
         num_cams, l, bs_, embed_dims = key.shape
         key = key.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)

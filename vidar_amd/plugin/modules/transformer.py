@@ -8,6 +8,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ..utils.host import const_tensor, to_device_async
+
 from ..bricks import rotate_nearest, xavier_init
 from ..registry import TRANSFORMER, build_transformer_layer_sequence
 from .spatial_cross_attention import MSDeformableAttention3D
@@ -70,7 +72,7 @@ class PerceptionTransformer(nn.Module):
         delta_lidar = np.array([np.linalg.inv(rot[i]) @ delta_global[i] for i in range(bs)])
         shift_y = delta_lidar[:, 1] / grid_length[0] / bev_h * self.use_shift
         shift_x = delta_lidar[:, 0] / grid_length[1] / bev_w * self.use_shift
-        shift = bev_queries.new_tensor(np.array([shift_x, shift_y])).permute(1, 0)
+        shift = to_device_async(np.array([shift_x, shift_y]).T, bev_queries.device, bev_queries.dtype)
 
         if prev_bev is not None:
             if prev_bev.shape[1] == bev_h * bev_w:
@@ -84,7 +86,7 @@ class PerceptionTransformer(nn.Module):
                     rotated.append(t.permute(1, 2, 0).reshape(bev_h * bev_w, -1))
                 prev_bev = torch.stack(rotated, 1)
 
-        can_bus = bev_queries.new_tensor(np.array([m["can_bus"] for m in img_metas]))
+        can_bus = to_device_async(np.array([m["can_bus"] for m in img_metas]), bev_queries.device, bev_queries.dtype)
         can_bus = self.can_bus_mlp(can_bus)[None, :, :]
         bev_queries = bev_queries + can_bus * self.use_can_bus
 
@@ -98,9 +100,9 @@ class PerceptionTransformer(nn.Module):
             feat = feat + self.level_embeds[None, None, lvl:lvl + 1, :].to(feat.dtype)
             feat_flatten.append(feat)
         feat_flatten = torch.cat(feat_flatten, 2)
-        spatial_shapes = torch.as_tensor(spatial_shapes, dtype=torch.long, device=bev_pos.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)),
-                                       spatial_shapes.prod(1).cumsum(0)[:-1]))
+        sizes = [h * w for h, w in spatial_shapes]
+        level_start_index = const_tensor([sum(sizes[:i]) for i in range(len(sizes))], bev_pos.device, torch.long)
+        spatial_shapes = const_tensor(spatial_shapes, bev_pos.device, torch.long)
         feat_flatten = feat_flatten.permute(0, 2, 1, 3)        # [cam, sum(hw), bs, c]
         return self.encoder(bev_queries, feat_flatten, feat_flatten, bev_h=bev_h, bev_w=bev_w,
                             bev_pos=bev_pos, spatial_shapes=spatial_shapes,

@@ -4,6 +4,8 @@ projects/mmdet3d_plugin/bevformer/modules/vidar_decoder.py:25-516."""
 from __future__ import annotations
 
 import torch
+
+from ..utils.host import const_tensor
 import torch.nn as nn
 
 from ..bricks import constant_init, xavier_init
@@ -62,9 +64,9 @@ class PredictionTransformerLayer(MyCustomBaseTransformerLayer):
         bs, num_frames, prev_tokens, prev_dims = prev_feats.shape
         assert prev_tokens == bev_h * bev_w
         dev = query.device
-        self_shapes = torch.tensor([[bev_h, bev_w]], device=dev)
-        self_lsi = torch.tensor([0], device=dev)
-        cross_shapes = torch.tensor([[bev_h, bev_w]] * num_frames, device=dev)
+        self_shapes = const_tensor([[bev_h, bev_w]], dev, torch.int64)
+        self_lsi = const_tensor([0], dev, torch.int64)
+        cross_shapes = const_tensor([[bev_h, bev_w]] * num_frames, dev, torch.int64)
         cross_lsi = torch.cat((cross_shapes.new_zeros((1,)), cross_shapes.prod(1).cumsum(0)[:-1]))
         prev_feats = prev_feats.reshape(bs, num_frames * prev_tokens, prev_dims)
         for layer in self.operation_order:

@@ -107,8 +107,9 @@ DifferentiableVoxelRenderingV2 = DifferentiableVoxelRenderingLayerV2.apply
 
 def get_inside_mask(points, point_cloud_range):
     """closed-box membership of [..., 3] points (:146-160)."""
-    lo = points.new_tensor(point_cloud_range[:3])
-    hi = points.new_tensor(point_cloud_range[3:])
+    from .host import const_tensor
+    lo = const_tensor(point_cloud_range[:3], points.device, points.dtype)
+    hi = const_tensor(point_cloud_range[3:], points.device, points.dtype)
     return ((points[..., :3] >= lo) & (points[..., :3] <= hi)).all(-1)
 
 
