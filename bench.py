@@ -81,6 +81,13 @@ def cpu_baseline(config, threads, with_backbone=True, reduced=False):
     from vidar_amd.configs import get_config
     from vidar_amd.synthetic import fpn_features, make_sample
     torch.set_num_threads(threads)
+    # never drive the host out of memory: cap this child's address space at half of the host RAM
+    try:
+        import resource
+        total = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+        resource.setrlimit(resource.RLIMIT_AS, (total // 2, total // 2))
+    except (ImportError, ValueError, OSError):
+        pass
     div = 4 if reduced else 1
     cfg = get_config(config, bev_h=200 // div, bev_w=200 // div, with_backbone=with_backbone)
     torch.manual_seed(0); np.random.seed(0)

@@ -19,7 +19,13 @@ from . import msda as M
 
 
 def _msda_apply(value, shapes, lsi, loc, w, im2col_step=64):
-    return M.msda_grid_sample(value.float(), shapes, loc.float(), w.float())
+    v, l_, w_ = value.float(), loc.float(), w.float()
+    if l_.numel() > (1 << 22) and torch.is_grad_enabled() and (v.requires_grad or l_.requires_grad or w_.requires_grad):
+        # full-size launches (bench.py's cpu_baseline leg): the per-sample stack [B*H, C, Nq, L, P] that autograd
+        # would keep is ~2 GB per SCA call; recompute it in backward instead (same numbers, bounded memory)
+        from torch.utils.checkpoint import checkpoint
+        return checkpoint(lambda a, b, c: M.msda_grid_sample(a, shapes, b, c), v, l_, w_, use_reentrant=False)
+    return M.msda_grid_sample(v, shapes, l_, w_)
 
 
 def _knn_points(p1, p2, lengths1=None, lengths2=None, K=1, **kw):

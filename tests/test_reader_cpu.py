@@ -1,0 +1,135 @@
+"""CPU: the info-pkl reader (vidar_amd/data/reader.py) -- multi-sweep loading pinned against the reference's
+own CustomLoadPointsFromMultiSweeps text (tests/golden/make_loading_golden.py), voxel subsampling / image
+normalisation against their definitions, and a synthetic mini nuScenes on disk read end to end into the
+forward_train kwargs (through the same union2one that tests/test_assemble_cpu.py pins to the reference)."""
+import pickle
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = Path(__file__).parent / "golden"
+sys.path.insert(0, str(GOLD))
+
+
+@pytest.mark.parametrize("seed,n", [(0, 5), (1, 2), (2, 0), (3, 1)])
+def test_multi_sweep_loader_matches_reference_text(tmp_path, seed, n):
+    from make_loading_golden import synthetic_case
+    from vidar_amd.data.reader import load_multi_sweeps
+    gold = np.load(GOLD / "loading.npz")
+    key, sweeps, ts = synthetic_case(tmp_path, seed, n)
+    got = load_multi_sweeps(key, sweeps, ts, sweeps_num=2, ego_mask=(-0.8, -1.5, 0.8, 2.5),
+                            hard_sweeps_timestamp=0, random_select=False)
+    np.testing.assert_array_equal(got, gold[f"points{seed}"])
+
+
+def test_voxel_subsample_keeps_first_point_per_voxel_in_order():
+    from vidar_amd.data.reader import voxel_subsample
+    pts = np.array([[0.2, 0.2, 0.1, 1, 0], [0.3, 0.3, 0.3, 2, 0],      # same 1 m voxel -> first stays
+                    [60.0, 0.0, 0.0, 3, 0],                            # outside the range
+                    [-51.2, -51.2, -5.0, 4, 0],                        # on the lower corner: inside
+                    [51.2, 0.0, 0.0, 5, 0],                            # on the upper bound: outside
+                    [1.5, 0.2, 0.1, 6, 0], [0.1, 0.1, 0.9, 7, 0]], np.float32)
+    out = voxel_subsample(pts)
+    np.testing.assert_array_equal(out[:, 3], [1, 4, 6])
+    assert voxel_subsample(pts, max_voxels=2).shape[0] == 2
+    # 0.5 m voxels (vidar_full configs): the first two points now fall into different voxels
+    # (grid = round(102.4 / 0.5) = 205 cells: x = 51.2 lands in cell 204, inside)
+    np.testing.assert_array_equal(voxel_subsample(pts, voxel_size=(0.5, 0.5, 0.5))[:, 3], [1, 2, 4, 5, 6, 7])
+
+
+def test_image_loading_normalises_bgr_and_pads(tmp_path):
+    from PIL import Image
+    from vidar_amd.data.reader import load_images
+    rgb = np.random.default_rng(0).integers(0, 255, (45, 70, 3), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    img, shape = load_images([tmp_path / "a.png", tmp_path / "a.png"])
+    assert img.shape == (2, 3, 64, 96) and shape == (64, 96, 3)
+    bgr = rgb[..., ::-1].astype(np.float32) - np.array([103.530, 116.280, 123.675], np.float32)
+    np.testing.assert_allclose(img[0, :, :45, :70].numpy(), bgr.transpose(2, 0, 1), rtol=0, atol=1e-4)
+    assert float(img[0, :, 45:].abs().max()) == 0 and float(img[0, :, :, 70:].abs().max()) == 0
+
+
+def _mini_nuscenes(root, n_frames=9, cams=2):
+    """two scenes (6 + 3 frames) with lidar .bin files, sweeps and tiny camera images"""
+    rng = np.random.default_rng(5)
+    from PIL import Image
+    infos = []
+    for k in range(n_frames):
+        scene = "scene-a" if k < 6 else "scene-b"
+        lidar = root / f"lidar_{k}.bin"
+        rng.uniform(-40, 40, (500, 5)).astype(np.float32).tofile(lidar)
+        sw = root / f"sweep_{k}.bin"
+        rng.uniform(-40, 40, (300, 5)).astype(np.float32).tofile(sw)
+        cam_infos = {}
+        for c in range(cams):
+            p = root / f"img_{k}_{c}.png"
+            Image.fromarray(rng.integers(0, 255, (40, 64, 3), dtype=np.uint8)).save(p)
+            yaw = c * np.pi
+            cam_infos[f"CAM_{c}"] = dict(
+                data_path=str(p), cam_intrinsic=np.array([[50.0, 0, 32], [0, 50.0, 20], [0, 0, 1]]),
+                sensor2lidar_rotation=np.array([[np.cos(yaw), 0, np.sin(yaw)], [np.sin(yaw), 0, -np.cos(yaw)], [0, -1.0, 0]]) @ np.eye(3),
+                sensor2lidar_translation=np.array([0.5 * c, 0.0, 1.5]))
+        a = 0.05 * k
+        infos.append(dict(token=f"tok{k}", lidar_path=str(lidar), timestamp=int((100 + 0.5 * k) * 1e6),
+                          sweeps=[dict(data_path=str(sw), timestamp=int((100 + 0.5 * k - 0.05) * 1e6),
+                                       sensor2lidar_rotation=np.eye(3), sensor2lidar_translation=np.zeros(3))],
+                          ego2global_translation=[2.0 * k, 0.3 * k, 0.0],
+                          ego2global_rotation=[np.cos(a / 2), 0.0, 0.0, np.sin(a / 2)],
+                          lidar2ego_translation=[0.9, 0.0, 1.8], lidar2ego_rotation=[1.0, 0.0, 0.0, 0.0],
+                          prev="" if k in (0, 6) else f"tok{k - 1}", next="" if k in (5, n_frames - 1) else f"tok{k + 1}",
+                          scene_token=scene, can_bus=np.zeros(18), frame_idx=k if k < 6 else k - 6, cams=cam_infos))
+    order = rng.permutation(n_frames)                       # the reader must sort by timestamp
+    with open(root / "infos.pkl", "wb") as f:
+        pickle.dump(dict(infos=[infos[i] for i in order], metadata=dict(version="v1.0-mini")), f)
+    return root / "infos.pkl"
+
+
+def test_mini_dataset_end_to_end(tmp_path):
+    from vidar_amd.data.reader import ViDARSequenceDataset
+    ann = _mini_nuscenes(tmp_path)
+    ds = ViDARSequenceDataset(ann, queue_length=2, future_length=1, test_mode=False)
+    assert [i["token"] for i in ds.infos] == [f"tok{k}" for k in range(9)]
+    # train mode: every frame with 1 future frame in its own scene (template :44-68)
+    assert ds.usable_index == [0, 1, 2, 3, 4, 6, 7]
+    np.random.seed(0)
+    s = ds[3]                                               # index 3: history frames 1, 2 + current 3, future 4
+    assert s["img"].shape == (3, 2, 3, 64, 64)
+    assert sorted(s["img_metas"]) == [0, 1, 2]
+    m = s["img_metas"][2]
+    assert m["sample_idx"] == "tok3" and m["img_shape"] == [(64, 64, 3)] * 2
+    assert [s["img_metas"][t]["prev_bev_exists"] for t in range(3)] == [False, True, True]
+    assert m["future2ref_lidar_transform"].shape == (2, 4, 4) and len(m["lidar2img"]) == 2
+    gt = s["gt_points"].numpy()
+    assert gt.shape[1] == 5 and sorted(np.unique(gt[:, 4])) == [0, 1, 2, 3]     # 2 history + current + 1 future
+    assert gt.shape[0] < 4 * 800                            # sweeps merged, then one point per 1 m voxel
+    ego = (np.abs(gt[:, 0]) <= 0.8) & (gt[:, 1] >= -1.5) & (gt[:, 1] <= 2.5)
+    assert not ego.any()
+    # the scene boundary: a sample whose future would cross into scene-b does not exist; test mode needs history
+    dt = ViDARSequenceDataset(ann, queue_length=2, future_length=1, test_mode=True)
+    assert dt.usable_index == [2, 3, 4]
+    t = dt[0]
+    assert t["gt_points"].shape[1] == 5 and t["img"].shape[0] == 3
+
+
+def test_model_consumes_a_read_sample(tmp_path):
+    """reader -> collate -> ViDAR.forward_train kwargs (ops on the CPU oracle, tiny BEV)"""
+    from oracle import cpu_ops
+    from vidar_amd import train as T
+    from vidar_amd.configs import get_config
+    from vidar_amd.data.reader import ViDARSequenceDataset
+    from vidar_amd.synthetic import fpn_features
+    ann = _mini_nuscenes(tmp_path)
+    ds = ViDARSequenceDataset(ann, queue_length=4, future_length=1)
+    np.random.seed(0); torch.manual_seed(0)
+    s = ds[ds.usable_index.index(4)]
+    cfg = get_config("vidar_1_8_nusc_1future", bev_h=12, bev_w=12)
+    cfg["model"]["pts_bbox_head"]["transformer"]["num_cams"] = 2
+    cfg["model"]["pts_bbox_head"]["transformer"]["encoder"]["transformerlayers"]["attn_cfgs"][1]["num_cams"] = 2
+    model = T.build_model(cfg).train()
+    feats = fpn_features(0, 5, num_cams=2, shapes=[(8, 8), (4, 4), (2, 2), (1, 1)])
+    with cpu_ops.patched():
+        losses = model(return_loss=True, img_metas=[s["img_metas"]], gt_points=[s["gt_points"]], img_feats=feats)
+    assert all(torch.isfinite(v) for v in losses.values()) and len(losses) == 10

@@ -57,6 +57,12 @@ def bench_dvr(which):
             ms3 = timeit(lambda: dvr.render_forward(sigma, origin, points, tindex, [5, 16, 200, 200], "train"))
             report(f"A/B pad_mode={pad_mode} order={order} M=150000", ms, render_v2_ms=round(ms2, 4),
                    render_forward_ms=round(ms3, 4))
+    sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=1, rays_per_frame=30000))
+    for pad_mode in (0, 1, 2):
+        lib().vidar_dvxlr_set_pad_mode(pad_mode); lib().vidar_dvr_set_sort_min_waves(1024)
+        ms = timeit(lambda: dvxlr.render(sigma, origin, points, tindex), it=30)
+        ms2 = timeit(lambda: dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma), it=30)
+        report(f"A/B pad_mode={pad_mode} M=30000", ms, render_v2_ms=round(ms2, 4))
     lib().vidar_dvxlr_set_pad_mode(PAD_MODE_DEFAULT); lib().vidar_dvr_set_sort_min_waves(1024)
     for T, rpf in ((1, 30000), (5, 30000)):
         sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=T, rays_per_frame=rpf))

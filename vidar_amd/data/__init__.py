@@ -1,4 +1,7 @@
-"""Sample assembly between a frame loader and the model (the data format on
-the input side of the hot path).  No dataset reader lives here -- records are plain dicts."""
+"""The data format on the input side of the hot path: `assemble` turns per-frame
+records into the sample the detector consumes, `reader` produces those records from a nuScenes / OpenScene
+info pkl (images, multi-sweep lidar, voxel subsampling)."""
 from .assemble import (frame_index_lists, frame_meta_from_info, transform_matrix, union2one,
                        usable_indices)  # noqa: F401
+from .reader import (ViDARSequenceDataset, load_images, load_infos, load_multi_sweeps, load_points_file,  # noqa: F401
+                     voxel_subsample)

@@ -1,0 +1,188 @@
+"""nuScenes / OpenScene info-pkl reader feeding `assemble.union2one` -- the data format on the input side
+of the hot path.
+
+What the reference does with mmdet3d's Custom3DDataset + a pipeline of registered transforms
+(datasets/nuscenes_dataset.py:134-227, nuscenes_vidar_dataset_template.py:44-135,
+nuscenes_vidar_dataset_v1.py:38-203; config :279-330), restated as plain functions on numpy:
+  load_infos            Custom3DDataset.load_annotations (sorted by timestamp, load_interval)     [3P mmdet3d]
+  load_points_file      LoadPointsFromFile(load_dim=5, use_dim=5)                                  [3P mmdet3d]
+  load_multi_sweeps     CustomLoadPointsFromMultiSweeps (datasets/pipelines/loading.py:10-205)
+  voxel_subsample       CustomVoxelBasedPointSampler (loading.py:225-241) on mmdet3d's VoxelGenerator
+                        (first point of every occupied voxel, in order of first appearance)         [3P mmdet3d]
+  load_images           LoadMultiViewImageFromFiles(to_float32) + NormalizeMultiviewImage +
+                        PadMultiViewImage(size_divisor=32) (pipelines/transform_3d.py:8-95)         [3P mmcv imread]
+Not restated: PhotoMetricDistortionMultiViewImage / CropResizeFlipImage (host-side image augmentation of the
+training pipeline, config :308-311) -- `ViDARSequenceDataset(augment=...)` takes a callable for them.
+[3P] pieces follow the published behaviour of mmcv 1.4.0 / mmdet3d 0.17.1 (not vendored by the reference)."""
+from __future__ import annotations
+
+import copy
+import pickle
+from pathlib import Path
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .assemble import frame_index_lists, frame_meta_from_info, union2one, usable_indices
+
+IMG_NORM = dict(mean=[103.530, 116.280, 123.675], std=[1.0, 1.0, 1.0], to_rgb=False)     # config :50-51
+PC_RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+
+
+def load_infos(ann_file, load_interval: int = 1):
+    """-> (infos sorted by timestamp, every load_interval-th; metadata dict)"""
+    with open(ann_file, "rb") as f:
+        data = pickle.load(f)
+    infos = list(sorted(data["infos"], key=lambda e: e["timestamp"]))[::load_interval]
+    return infos, data.get("metadata", {})
+
+
+def load_points_file(path, load_dim: int = 5) -> np.ndarray:
+    p = str(path)
+    pts = np.load(p) if p.endswith(".npy") else np.fromfile(p, dtype=np.float32)
+    return np.copy(pts).reshape(-1, load_dim)
+
+
+def remove_close(points: np.ndarray, radius: float = 1.0, ego_mask=None) -> np.ndarray:
+    """drop |x|<r & |y|<r (loading.py:76-97), then the ego-vehicle box (:190-215; inclusive bounds)"""
+    close = (np.abs(points[:, 0]) < radius) & (np.abs(points[:, 1]) < radius)
+    points = points[~close]
+    if ego_mask is not None:
+        ego = ((ego_mask[0] <= points[:, 0]) & (ego_mask[2] >= points[:, 0])
+               & (ego_mask[1] <= points[:, 1]) & (ego_mask[3] >= points[:, 1]))
+        points = points[~ego]
+    return points
+
+
+def select_sweeps(sweeps: Sequence[dict], ts: float, sweeps_num: int, test_mode=False, random_select=True):
+    """loading.py:99-116"""
+    if len(sweeps) <= sweeps_num:
+        return np.arange(len(sweeps))
+    if test_mode:
+        return np.arange(sweeps_num)
+    if random_select:
+        return np.random.choice(len(sweeps), sweeps_num, replace=False)
+    gap = np.abs(np.array([s["timestamp"] for s in sweeps]) / 1e6 - ts)
+    return np.argsort(gap)[:sweeps_num]
+
+
+def load_multi_sweeps(points: np.ndarray, sweeps: Sequence[dict], ts: float, sweeps_num=2,
+                      use_dim=(0, 1, 2, 3, 4), pad_empty_sweeps=True, remove_close_pts=True, ego_mask=None,
+                      hard_sweeps_timestamp=0, random_select=False, test_mode=False, load_dim=5,
+                      loader: Callable = load_points_file) -> np.ndarray:
+    """key frame (time channel 0, NOT filtered) + `sweeps_num` sweeps moved into the key frame's lidar frame
+    (loading.py:118-168), time channel overwritten by `hard_sweeps_timestamp` when given (:217-223)."""
+    points = np.array(points, dtype=np.float32, copy=True)
+    points[:, 4] = 0
+    parts = [points]
+    if pad_empty_sweeps and len(sweeps) == 0:
+        for _ in range(sweeps_num):
+            parts.append(remove_close(points, ego_mask=ego_mask) if remove_close_pts else points)
+    else:
+        for idx in select_sweeps(sweeps, ts, sweeps_num, test_mode, random_select):
+            sweep = sweeps[idx]
+            p = loader(sweep["data_path"], load_dim)
+            if remove_close_pts:
+                p = remove_close(p, ego_mask=ego_mask)
+            p[:, :3] = p[:, :3] @ np.asarray(sweep["sensor2lidar_rotation"]).T
+            p[:, :3] += np.asarray(sweep["sensor2lidar_translation"])
+            p[:, 4] = ts - sweep["timestamp"] / 1e6
+            parts.append(p.astype(np.float32))
+    out = np.concatenate(parts, 0)[:, list(use_dim)]
+    if hard_sweeps_timestamp is not None:
+        out[:, 4] = hard_sweeps_timestamp
+    return out
+
+
+def voxel_subsample(points: np.ndarray, voxel_size=(1.0, 1.0, 1.0), point_cloud_range=PC_RANGE,
+                    max_voxels: int = 50000) -> np.ndarray:
+    """first point of every occupied voxel, voxels in order of first appearance, points outside the range
+    dropped, at most `max_voxels` voxels -- mmdet3d VoxelGenerator(max_num_points=1) as used through
+    CustomVoxelBasedPointSampler._sample_points (returns the un-padded voxel array, loading.py:226-241)."""
+    rng = np.asarray(point_cloud_range, np.float32)
+    vs = np.asarray(voxel_size, np.float32)
+    grid = np.round((rng[3:] - rng[:3]) / vs).astype(np.int64)
+    c = np.floor((points[:, :3] - rng[:3]) / vs).astype(np.int64)
+    ok = ((c >= 0) & (c < grid)).all(1)
+    key = (c[:, 2] * grid[1] + c[:, 1]) * grid[0] + c[:, 0]
+    idx = np.nonzero(ok)[0]
+    _, first = np.unique(key[idx], return_index=True)
+    keep = np.sort(idx[first])[:max_voxels]
+    return points[keep]
+
+
+def load_images(paths: Sequence, mean=IMG_NORM["mean"], std=IMG_NORM["std"], to_rgb=IMG_NORM["to_rgb"],
+                size_divisor: int = 32):
+    """-> (float32 [cams, 3, H_pad, W_pad], padded shape (H, W, 3)).  Channel order BGR like mmcv.imread
+    (cv2); `to_rgb` flips it before normalising like mmcv.imnormalize; zero padding at bottom / right."""
+    from PIL import Image
+    imgs = []
+    for p in paths:
+        if str(p).endswith(".npy"):
+            a = np.load(p).astype(np.float32)                        # already BGR float (test fixtures)
+        else:
+            a = np.asarray(Image.open(p).convert("RGB"), dtype=np.float32)[..., ::-1]
+        if to_rgb:
+            a = a[..., ::-1]
+        a = (a - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+        h, w = a.shape[:2]
+        H = (h + size_divisor - 1) // size_divisor * size_divisor
+        W = (w + size_divisor - 1) // size_divisor * size_divisor
+        pad = np.zeros((H, W, 3), np.float32)
+        pad[:h, :w] = a
+        imgs.append(pad)
+    arr = np.stack(imgs)                                             # [cams, H, W, 3]
+    return torch.from_numpy(np.ascontiguousarray(arr.transpose(0, 3, 1, 2))), tuple(arr.shape[1:])
+
+
+class ViDARSequenceDataset:
+    """`dataset[i]` -> dict(img [T, cams, 3, H, W], img_metas {t: meta}, gt_points [P, 5]): the forward_train /
+    forward_test kwargs of one sample (collate = add the batch dimension).
+    NuScenesViDARDatasetV1 with the released pipeline (config :279-330, :332-375)."""
+
+    def __init__(self, ann_file, data_root="", queue_length=4, future_length=1, test_mode=False,
+                 load_interval=1, load_frame_interval=None, rand_frame_interval=(1,),
+                 ego_mask=(-0.8, -1.5, 0.8, 2.5), sweeps_num=2, voxel_size=(1.0, 1.0, 1.0),
+                 point_cloud_range=PC_RANGE, max_voxels=50000, dataset="nuscenes",
+                 augment: Optional[Callable] = None):
+        self.infos, self.metadata = load_infos(ann_file, load_interval)
+        self.data_root, self.dataset = str(data_root), dataset
+        self.queue_length, self.future_length, self.test_mode = queue_length, future_length, test_mode
+        self.rand_frame_interval, self.ego_mask = tuple(rand_frame_interval), ego_mask
+        self.sweeps_num, self.voxel_size = sweeps_num, voxel_size
+        self.point_cloud_range, self.max_voxels = point_cloud_range, max_voxels
+        self.augment = augment
+        self.usable_index = usable_indices(self.infos, future_length, queue_length, test_mode, load_frame_interval)
+
+    def __len__(self):
+        return len(self.usable_index)
+
+    def _path(self, p):
+        return str(Path(self.data_root) / p) if self.data_root and not Path(p).is_absolute() else str(p)
+
+    def frame(self, index, with_images=True):
+        """one frame through the pipeline -> record dict(img, points, img_metas)"""
+        meta = frame_meta_from_info(copy.deepcopy(self.infos[index]), self.dataset, self.data_root)
+        pts = load_points_file(self._path(meta["pts_filename"]))
+        if not self.test_mode:                                       # train pipeline: sweeps + voxel subsample
+            sweeps = [dict(s, data_path=self._path(s["data_path"])) for s in meta.get("sweeps", [])]
+            pts = load_multi_sweeps(pts, sweeps, meta["timestamp"], self.sweeps_num, ego_mask=self.ego_mask)
+            pts = voxel_subsample(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
+        rec = dict(points=torch.from_numpy(np.ascontiguousarray(pts)), img_metas=meta)
+        if with_images:
+            img, shape = load_images([self._path(p) for p in meta["img_filename"]])
+            n = img.shape[0]
+            meta.update(img_shape=[shape] * n, pad_shape=[shape] * n, img_norm_cfg=dict(IMG_NORM))
+            rec["img"] = img
+            if self.augment is not None:
+                rec = self.augment(rec)
+        return rec
+
+    def __getitem__(self, i):
+        index = self.usable_index[i]
+        interval = int(np.random.choice(self.rand_frame_interval, 1)[0])
+        prev, fut = frame_index_lists(index, self.queue_length, self.future_length, interval, len(self.infos))
+        previous_queue = [self.frame(k) for k in prev]
+        future_queue = [self.frame(k, with_images=False) for k in fut]
+        return union2one(previous_queue, future_queue, self.future_length, self.ego_mask)

@@ -72,7 +72,7 @@ class ViDARHeadTemplate(nn.Module):
         bev_mask = torch.zeros((bs, self.bev_h, self.bev_w), device=bev_queries.device).to(dtype)
         bev_pos = self.positional_encoding(bev_mask).to(dtype)
         can_bus = np.array([m["future_can_bus"][target_frame_index] for m in img_metas])[:, self.can_bus_dims]
-        can_bus = torch.from_numpy(can_bus).to(dtype).to(bev_pos.device)
+        can_bus = to_device_async(can_bus, bev_pos.device, dtype)
         bev_queries_input = bev_queries + self.can_bus_mlp(can_bus).unsqueeze(1)
         prev_features_input = prev_features + self.prev_frame_embedding[None, :, None, :]
         return self.transformer(prev_features_input, bev_queries_input, tgt_points=tgt_points,

@@ -12,13 +12,49 @@ import torch
 _CONST: dict = {}
 
 
+class _PinnedArena:
+    """One pinned staging buffer per process, bump-allocated and reused round-robin.  `tensor.pin_memory()`
+    per copy is not an option: a pinned block can only be recycled once its copy has executed, the host runs
+    far ahead of the GPU, so every call ends in a fresh hipHostMalloc (a slow, serialising driver call).
+    A slice is overwritten only after a full lap; the event recorded at the previous wrap-around is waited on
+    first (it completed long ago: every step reads the visible-query lengths back, which drains the stream)."""
+
+    def __init__(self, nbytes=8 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.pos = 0
+        self.lap_event = None
+
+    def stage(self, src):
+        """copy the CPU tensor `src` into the arena -> pinned view with src's dtype / shape"""
+        n = src.numel() * src.element_size()
+        if n > self.buf.numel() // 4:
+            return src.pin_memory()
+        start = (self.pos + 15) & ~15
+        if start + n > self.buf.numel():
+            if self.lap_event is not None:
+                self.lap_event.synchronize()
+            self.lap_event = torch.cuda.Event()
+            self.lap_event.record()
+            start = 0
+        self.pos = start + n
+        view = self.buf[start:start + n].view(src.dtype).view(src.shape)
+        view.copy_(src)
+        return view
+
+
+_ARENA = None
+
+
 def to_device_async(array, device, dtype=torch.float32):
-    """numpy / nested list -> device tensor via pinned memory, non-blocking."""
+    """numpy / nested list -> device tensor via the pinned arena, non-blocking."""
+    global _ARENA
     device = torch.device(device)
     t = torch.as_tensor(np.ascontiguousarray(np.asarray(array)), dtype=dtype)
     if device.type != "cuda":
         return t.to(device)
-    return t.pin_memory().to(device, non_blocking=True)
+    if _ARENA is None:
+        _ARENA = _PinnedArena()
+    return _ARENA.stage(t).to(device, non_blocking=True)
 
 
 def const_tensor(values, device, dtype=torch.float32):
