@@ -63,15 +63,25 @@ int vidar_dvr_init_f32(const float* points, const float* tindex, float* occupanc
  * ------------------------------------------------------------------------- */
 int vidar_dvxlr_max_d(void); /* 1026, third_lib/dvxlr/dvxlr.cu:10 */
 
+/* Precision contract of the dvr / dvxlr family: the voxel traversal (tMax / tDelta, axis choice, voxel
+ * indices, gt_dist) is IEEE fp64 in the reference's operation order, no FMA contraction -> index lists
+ * and gt_dist are bit-exact.  The transmittance of the online ray integral is evaluated as
+ * expf((float)(-cumulative_sigma_dt)) -- fp32, where the reference calls the fp64 exp -- because every
+ * output it feeds (pred_dist, dd_dsigma, grad_sigma) is stored as fp32 anyway (the reference allocates
+ * float outputs, dvxlr.cu:490-493); those values agree with the reference to 2e-5 relative
+ * (tests/test_dvr_gpu.py), not bit for bit.  Only _f32 entry points exist for the same reason: fp64
+ * tensor arguments make the reference itself fail in packed_accessor32. */
+
 /* tuning/A-B switch of the dvr / dvxlr march launches: a launch with more than `min_waves` waves of
  * 64 rays (default 1024 = one per SIMD) ranks the rays of each 256-ray workgroup by estimated
  * length before walking them; 0 = always, INT_MAX = never.  Results do not depend on it.
  * Returns the previous value. */
 int vidar_dvr_set_sort_min_waves(int min_waves);
 /* tuning/A-B switch of dvxlr.render / render_v2: 0 = the finish pass pads the [1026] rows itself,
- * 1 (default) = one device fill ahead of the march, the finish pass only touches the live prefixes,
- * 2 = like 1, with the fills of the rows the march never touches on a forked stream (unmeasured).
- * Results do not depend on it.  Returns the previous value. */
+ * 1 (default) = one device fill ahead of the march, the finish pass only touches the live prefixes.
+ * Results do not depend on it (tests/test_dvr_gpu.py runs every case under both).  Both switches are plain
+ * process-wide ints read at launch time: set them before concurrent use, not during.
+ * Returns the previous value. */
 int vidar_dvxlr_set_pad_mode(int mode);
 
 /* dvxlr.render(sigma, origin, points, tindex) -> [pred_dist, gt_dist, dd_dsigma, indices]
@@ -155,6 +165,27 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        const float* attn_weight, const float* grad_out, float* grad_value,
                        float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
                        int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fused operand preparation (csrc/msda.hip): the op consumes the raw outputs of the sampling_offsets and
+ * attention_weights Linear layers instead of prepared locations / weights, replacing the softmax, the
+ * division by the level size, the reference-point add and the (TSA) permute copies of
+ * temporal_self_attention.py:218-245, spatial_cross_attention.py:359-383, vidar_decoder.py:463-490.
+ *   off_raw [bs,Nq,H,Qn,L,P,2] f32, logit_raw [bs,Nq,H,Qn,L*P] f32, ref [bs*Qn,Nq,R,2] f32,
+ *   value [bs*Qn,Nv,H,C]; loc = ref[.., r, :] + off / (W_l, H_l) with r = level (mode 0, R == L) or
+ *   point % R (mode 1, P % R == 0); w = softmax over L*P.
+ * fwd writes out [bs*Qn,Nq,H*C] and the prepared operands loc_out [bs*Qn,Nq,H,L,P,2] / w_out [bs*Qn,Nq,H,L,P]
+ * (what the backward needs); bwd takes those and writes grad_value (zeroed + accumulated),
+ * grad_off_raw, grad_logit_raw (fully written, raw layouts).  workspace as for vidar_msda_bwd_f32 with
+ * B = bs*Qn. */
+int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start_index, const float* off_raw, const float* logit_raw,
+                             const float* ref, float* loc_out, float* w_out, float* out, int bs, int Qn, int Nv,
+                             int H, int C, int Nq, int L, int P, int R, int mode, void* stream);
+int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start_index, const float* sampling_loc,
+                             const float* attn_weight, const float* grad_out, float* grad_value,
+                             float* grad_off_raw, float* grad_logit_raw, int bs, int Qn, int Nv, int H, int C,
+                             int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * BEV-encoder bookkeeping for F frames at once.  Replaces BEVFormerEncoder.point_sampling

@@ -13,15 +13,14 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
 
 
-PAD_MODE = {"plain": 0, "ranked": 0, "ranked-prefill": 1, "ranked-forked": 2}
+PAD_MODE = {"plain": 0, "ranked": 0, "ranked-prefill": 1}
 
 
 @pytest.fixture(autouse=True, params=list(PAD_MODE))
 def march_order(request):
     """every test runs under each launch variant: default, with the rays of each workgroup ranked
     by estimated length (what launches above 65k rays do), and with the device-fill-first padding
-    of dvxlr.render (mode 1), or with the dd_dsigma fill forked onto a side stream and joined before
-    the finish pass (mode 2) -- results must not depend on it."""
+    of dvxlr.render (mode 1) -- results must not depend on it."""
     from vidar_amd._lib import lib
     prev = lib().vidar_dvr_set_sort_min_waves(1 << 30 if request.param == "plain" else 0)
     prev_pad = lib().vidar_dvxlr_set_pad_mode(PAD_MODE[request.param])

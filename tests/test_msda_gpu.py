@@ -155,3 +155,43 @@ def test_binned_workspace_contract():
     rc = lib().vidar_msda_bwd_f32(ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(go), ptr(gv), ptr(gl),
                                   ptr(gw), 2, 400, 8, 32, 400, 1, 4, ptr(ws), ctypes.c_size_t(64), stream_of(go))
     assert rc == -22
+
+
+FUSED = [  # name, bs, Qn, shapes, Nq, P, mode, R
+    ("tsa_like", 2, 2, [(20, 20)], 400, 4, 0, 1),
+    ("pred_cross_2_levels", 1, 1, [(12, 12), (12, 12)], 144, 4, 0, 2),
+    ("sca_like", 3, 1, [(12, 20), (6, 10), (3, 5), (2, 3)], 333, 8, 1, 4),
+    ("sca_two_heads", 2, 1, [(12, 20), (6, 10)], 50, 8, 1, 4),
+    ("tsa_binned_size", 1, 2, [(100, 100)], 10000, 4, 0, 1),           # 640 k samples -> binned backward
+]
+
+
+@pytest.mark.parametrize("case", FUSED, ids=[c[0] for c in FUSED])
+def test_fused_operand_preparation_matches_the_reference_tensor_program(case):
+    """vidar_msda_fused_{fwd,bwd}: raw sampling_offsets / attention_weights Linear outputs in, gradients w.r.t.
+    them out -- against the reference's own tensor program (softmax, /normalizer, + reference points, queue
+    permutes) in fp64 on the CPU followed by the gather oracle."""
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    name, bs, Qn, shapes, Nq, P, mode, R = case
+    H = 2 if name == "sca_two_heads" else 8
+    L = len(shapes)
+    g = torch.Generator().manual_seed(len(name))
+    Nv = sum(h * w for h, w in shapes)
+    value = torch.randn(bs * Qn, Nv, H, 32, generator=g)
+    off_raw = torch.randn(bs, Nq, H * Qn * L * P * 2, generator=g) * 3.0            # pixels
+    logit_raw = torch.randn(bs, Nq, H * Qn * L * P, generator=g)
+    ref = torch.rand(bs * Qn, Nq, R, 2, generator=g) * 1.1 - 0.05
+    sh = torch.tensor(shapes, dtype=torch.int64)
+    lsi = M.level_start_index(shapes)
+    gout = torch.randn(bs * Qn, Nq, H * 32, generator=g)
+    v64, o64, l64 = (t.double().requires_grad_(True) for t in (value, off_raw, logit_raw))
+    loc, w = F.compose_operands(o64, l64, ref.double(), sh, H, Qn, L, P, mode)
+    want = M.msda_gather(v64, sh, loc, w)
+    gwant = torch.autograd.grad((want * gout.double()).sum(), [v64, o64, l64])
+    dv, do, dl = (t.cuda().requires_grad_(True) for t in (value, off_raw, logit_raw))
+    out = F.fused_deform_attn(dv, sh.cuda(), lsi.cuda(), do, dl, ref.cuda(), Qn, L, P, mode)
+    torch.testing.assert_close(out.detach().cpu().double(), want.detach(), rtol=1e-4, atol=2e-5)
+    got = torch.autograd.grad((out * gout.cuda()).sum(), [dv, do, dl])
+    for a, b, nm in zip(got, gwant, ["grad_value", "grad_off_raw", "grad_logit_raw"]):
+        scale = max(1.0, float(b.abs().max()))
+        torch.testing.assert_close(a.cpu().double(), b, rtol=3e-4, atol=3e-5 * scale, msg=lambda m: nm + m)

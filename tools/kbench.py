@@ -49,7 +49,7 @@ def bench_dvr(which):
     t = lambda a: torch.from_numpy(a).cuda()
     # A/B of the launch variants (results are identical, tests/test_dvr_gpu.py)
     sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=5, rays_per_frame=30000))
-    for pad_mode in (0, 1, 2):
+    for pad_mode in (0, 1):
         for thr, order in ((1 << 30, "plain"), (0, "ranked")):
             lib().vidar_dvxlr_set_pad_mode(pad_mode); lib().vidar_dvr_set_sort_min_waves(thr)
             ms = timeit(lambda: dvxlr.render(sigma, origin, points, tindex))
@@ -58,7 +58,7 @@ def bench_dvr(which):
             report(f"A/B pad_mode={pad_mode} order={order} M=150000", ms, render_v2_ms=round(ms2, 4),
                    render_forward_ms=round(ms3, 4))
     sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=1, rays_per_frame=30000))
-    for pad_mode in (0, 1, 2):
+    for pad_mode in (0, 1):
         lib().vidar_dvxlr_set_pad_mode(pad_mode); lib().vidar_dvr_set_sort_min_waves(1024)
         ms = timeit(lambda: dvxlr.render(sigma, origin, points, tindex), it=30)
         ms2 = timeit(lambda: dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma), it=30)

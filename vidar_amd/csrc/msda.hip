@@ -72,10 +72,135 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ p, int64_t o) {
   return o >= 0 ? *reinterpret_cast<const float4*>(p + o) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused operand preparation.  The modules feed the op with the raw outputs of two Linear layers:
+//   off_raw   [bs, Nq, H, Qn, L, P, 2]   sampling offsets in pixels          (sampling_offsets GEMM)
+//   logit_raw [bs, Nq, H, Qn, L*P]       attention logits                    (attention_weights GEMM)
+// and reference points ref [bs*Qn, Nq, R, 2]; the reference turns them into the op's operands with a
+// softmax, a division by the level size, an add and (TemporalSelfAttention, Qn = 2 BEV queue entries)
+// two permute copies (temporal_self_attention.py:218-245, spatial_cross_attention.py:359-383,
+// vidar_decoder.py:463-490):
+//   loc[b', q, h, l, p] = ref[b', q, r(l, p)] + off / (W_l, H_l),  r = l (mode 0) or p % R (mode 1, SCA:
+//   point p belongs to pillar anchor p % R), b' = b * Qn + qn;   w = softmax over the L*P logits.
+// Here the staging phase of the kernels does that arithmetic in LDS.  The forward also writes loc / w
+// (the tensors the unfused path would have saved for the backward); the backward turns grad_loc / grad_w
+// into grad_off_raw / grad_logit_raw in its store phase.
+// ---------------------------------------------------------------------------------------------
+struct Prep {
+  const float* off_raw;      // nullptr: plain operands (loc / w given)
+  const float* logit_raw;
+  const float* ref;
+  float* loc_out;            // forward: saved operands;   backward: unused
+  float* w_out;
+  float* g_off_raw;          // backward outputs
+  float* g_logit_raw;
+  int Qn, R, mode;
+};
+
+// index of (item, lp) inside the raw [bs, Nq, H, Qn, LP] layout
+__device__ __forceinline__ int64_t raw_index(int64_t item, int lp, int H, int Nq, int LP, int Qn) {
+  const int h = (int)(item % H);
+  const int64_t bq = item / H;
+  const int64_t q = bq % Nq, bp = bq / Nq;
+  const int64_t b = bp / Qn, qn = bp % Qn;
+  return ((((b * Nq + q) * H + h) * Qn + qn) * LP) + lp;
+}
+
+// stage operands of `nvalid` items starting at item0 into s_loc [n][LP*2] / s_w [n][LP]
+template <int kThr>
+__device__ __forceinline__ void stage_operands(const Prep& pr, const float* __restrict__ loc,
+                                               const float* __restrict__ attw,
+                                               const int64_t* __restrict__ shapes, float* s_loc, float* s_w,
+                                               int64_t item0, int nvalid, int H, int Nq, int L, int P) {
+  const int LP = L * P;
+  if (pr.off_raw == nullptr) {
+    for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThr) s_loc[i] = loc[item0 * LP * 2 + i];
+    for (int i = threadIdx.x; i < nvalid * LP; i += kThr) s_w[i] = attw[item0 * LP + i];
+    __syncthreads();
+    return;
+  }
+  for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
+    const int it = i / LP, lp = i - it * LP;
+    const int64_t item = item0 + it;
+    const int64_t raw = raw_index(item, lp, H, Nq, LP, pr.Qn);
+    const int l = lp / P, p = lp - l * P;
+    const int r = pr.mode == 0 ? l : p % pr.R;
+    const float2 o = reinterpret_cast<const float2*>(pr.off_raw)[raw];
+    const float2 rf = reinterpret_cast<const float2*>(pr.ref)[(item / H) * pr.R + r];
+    s_loc[2 * i] = rf.x + o.x / (float)shapes[2 * l + 1];
+    s_loc[2 * i + 1] = rf.y + o.y / (float)shapes[2 * l];
+    s_w[i] = pr.logit_raw[raw];
+  }
+  __syncthreads();
+  // softmax over the LP logits of every item: 8 lanes per item, values in registers (LP <= 64)
+  const int nlan = 8;
+  for (int it = threadIdx.x / nlan; it < nvalid; it += kThr / nlan) {
+    const int sub = threadIdx.x % nlan;
+    float e[kMaxLP / 8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kMaxLP / 8; ++k) {
+      const int lp = sub + k * nlan;
+      e[k] = lp < LP ? s_w[it * LP + lp] : -INFINITY;
+      m = fmaxf(m, e[k]);
+    }
+#pragma unroll
+    for (int d = 1; d < nlan; d <<= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxLP / 8; ++k) {
+      const int lp = sub + k * nlan;
+      e[k] = lp < LP ? expf(e[k] - m) : 0.f;
+      sum += e[k];
+    }
+#pragma unroll
+    for (int d = 1; d < nlan; d <<= 1) sum += __shfl_xor(sum, d, 64);
+#pragma unroll
+    for (int k = 0; k < kMaxLP / 8; ++k) {
+      const int lp = sub + k * nlan;
+      if (lp < LP) s_w[it * LP + lp] = e[k] / sum;
+    }
+  }
+  __syncthreads();
+  if (pr.loc_out != nullptr) {
+    for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThr) pr.loc_out[item0 * LP * 2 + i] = s_loc[i];
+    for (int i = threadIdx.x; i < nvalid * LP; i += kThr) pr.w_out[item0 * LP + i] = s_w[i];
+  }
+}
+
+// store phase of the backward kernels: s_loc / s_w hold grad_loc / grad_w of `nvalid` items
+template <int kThr>
+__device__ __forceinline__ void store_grads(const Prep& pr, const float* __restrict__ attw,
+                                            const int64_t* __restrict__ shapes, float* __restrict__ grad_loc,
+                                            float* __restrict__ grad_w, float* s_loc, float* s_w, float* s_dot,
+                                            int64_t item0, int nvalid, int H, int Nq, int L, int P) {
+  const int LP = L * P;
+  if (pr.g_off_raw == nullptr) {
+    for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThr) grad_loc[item0 * LP * 2 + i] = s_loc[i];
+    for (int i = threadIdx.x; i < nvalid * LP; i += kThr) grad_w[item0 * LP + i] = s_w[i];
+    return;
+  }
+  // softmax backward: g_logit = w * (g_w - sum_j w_j g_w_j);  d loc / d off = 1 / (W_l, H_l)
+  for (int it = threadIdx.x; it < nvalid; it += kThr) {
+    float dot = 0.f;
+    for (int lp = 0; lp < LP; ++lp) dot += attw[(item0 + it) * LP + lp] * s_w[it * LP + lp];
+    s_dot[it] = dot;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
+    const int it = i / LP, lp = i - it * LP;
+    const int64_t raw = raw_index(item0 + it, lp, H, Nq, LP, pr.Qn);
+    const int l = lp / P;
+    pr.g_logit_raw[raw] = attw[item0 * LP + i] * (s_w[i] - s_dot[it]);
+    reinterpret_cast<float2*>(pr.g_off_raw)[raw] =
+        make_float2(s_loc[2 * i] / (float)shapes[2 * l + 1], s_loc[2 * i + 1] / (float)shapes[2 * l]);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
-    float* __restrict__ out, int Nv, int H, int Nq, int L, int P, int64_t n_items, int nblocks) {
+    float* __restrict__ out, int Nv, int H, int Nq, int L, int P, int64_t n_items, int nblocks, Prep pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
   float* s_loc = smem;                       // [kItems][LP*2]
@@ -84,10 +209,7 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
   if (blk >= nblocks) return;
   const int64_t item0 = (int64_t)blk * kItems;
   const int nvalid = (int)min((int64_t)kItems, n_items - item0);
-  // coalesced staging
-  for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) s_loc[i] = loc[item0 * LP * 2 + i];
-  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) s_w[i] = attw[item0 * LP + i];
-  __syncthreads();
+  stage_operands<kThreads>(pr, loc, attw, shapes, s_loc, s_w, item0, nvalid, H, Nq, L, P);   // coalesced
   const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
   if (it >= nvalid) return;
   const int64_t item = item0 + it;
@@ -144,11 +266,12 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ grad_out, float* __restrict__ grad_value,
     float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv, int H, int Nq, int L, int P,
-    int64_t n_items, int nblocks) {
+    int64_t n_items, int nblocks, Prep pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
   float* s_loc = smem;                         // [kBItems][LP*2]  in: loc, out: grad_loc
   float* s_w = smem + kBItems * LP * 2;        // [kBItems][LP]    in: w,   out: grad_w
+  float* s_dot = s_w + kBItems * LP;           // [kBItems]
   const int blk = xcd_remap(blockIdx.x, nblocks);
   if (blk >= nblocks) return;
   const int64_t item0 = (int64_t)blk * kBItems;
@@ -202,8 +325,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) grad_loc[item0 * LP * 2 + i] = s_loc[i];
-  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) grad_w[item0 * LP + i] = s_w[i];
+  store_grads<kThreads>(pr, attw, shapes, grad_loc, grad_w, s_loc, s_w, s_dot, item0, nvalid, H, Nq, L, P);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -438,11 +560,12 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv,
-    int H, int Nq, int L, int P, int64_t n_items, int nblocks) {
+    int H, int Nq, int L, int P, int64_t n_items, int nblocks, Prep pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
   float* s_loc = smem;                       // [kItems][LP*2]  in: loc, out: grad_loc
   float* s_w = smem + kItems * LP * 2;       // [kItems][LP]    in: w,   out: grad_w
+  float* s_dot = s_w + kItems * LP;          // [kItems]
   const int blk = xcd_remap(blockIdx.x, nblocks);
   if (blk >= nblocks) return;
   const int64_t item0 = (int64_t)blk * kItems;
@@ -495,8 +618,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) grad_loc[item0 * LP * 2 + i] = s_loc[i];
-  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) grad_w[item0 * LP + i] = s_w[i];
+  store_grads<kThreads>(pr, attw, shapes, grad_loc, grad_w, s_loc, s_w, s_dot, item0, nvalid, H, Nq, L, P);
 }
 
 // workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks: 4]
@@ -531,11 +653,10 @@ inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
 
 extern "C" {
 
-int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
-                       const int64_t* level_start_index, const float* sampling_loc,
-                       const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq,
-                       int L, int P, void* stream) {
-  VIDAR_ENTER();
+static int msda_fwd_launch(const float* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start_index, const float* sampling_loc,
+                           const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq, int L,
+                           int P, const Prep& pr, void* stream) {
   if (msda_bad(B, Nv, H, C, Nq, L, P)) return VIDAR_ERR_BAD_ARG;
   const int64_t n_items = (int64_t)B * Nq * H;
   if (n_items == 0) return 0;
@@ -544,22 +665,16 @@ int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
   const size_t lds = sizeof(float) * kItems * L * P * 3;
   hipLaunchKernelGGL(msda_fwd_kernel, dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, Nv, H, Nq, L,
-                     P, n_items, nblocks);
+                     P, n_items, nblocks, pr);
   return vidar_last_error();
 }
 
-size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P) {
-  if (B <= 0 || Nv <= 0 || H <= 0 || Nq <= 0 || L <= 0 || P <= 0) return 0;
-  const BinPlan p = bin_plan(B, Nv, H, Nq, L, P);
-  return p.ok ? p.bytes : 0;
-}
-
-int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
-                       const int64_t* level_start_index, const float* sampling_loc,
-                       const float* attn_weight, const float* grad_out, float* grad_value,
-                       float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
-                       int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream) {
-  VIDAR_ENTER();
+static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start_index, const float* sampling_loc,
+                           const float* attn_weight, const float* grad_out, float* grad_value,
+                           float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
+                           int Nq, int L, int P, void* workspace, size_t workspace_bytes, const Prep& pr,
+                           void* stream) {
   if (msda_bad(B, Nv, H, C, Nq, L, P)) return VIDAR_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
   const size_t vbytes = sizeof(float) * (size_t)B * Nv * H * C;
@@ -595,19 +710,78 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        Nv, H, L, P);
     const int nblocks = (int)((n_items + kItems - 1) / kItems);
     const int grid = ((nblocks + 7) / 8) * 8;
-    const size_t lds = sizeof(float) * kItems * L * P * 3;
+    const size_t lds = sizeof(float) * (kItems * L * P * 3 + kItems);
     hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
-                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks);
+                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
     return vidar_last_error();
   }
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
   const int grid = ((nblocks + 7) / 8) * 8;
-  const size_t lds = sizeof(float) * kBItems * L * P * 3;
+  const size_t lds = sizeof(float) * (kBItems * L * P * 3 + kBItems);
   hipLaunchKernelGGL(msda_bwd_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                      level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
-                     grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks);
+                     grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
   return vidar_last_error();
+}
+
+static bool prep_bad(int bs, int Qn, int R, int mode, int L, int P) {
+  return bs < 0 || Qn <= 0 || R <= 0 || (mode != 0 && mode != 1) || (mode == 0 && R != L) ||
+         (mode == 1 && P % R != 0);
+}
+
+int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* sampling_loc,
+                       const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq,
+                       int L, int P, void* stream) {
+  VIDAR_ENTER();
+  return msda_fwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, B, Nv, H, C,
+                         Nq, L, P, Prep{}, stream);
+}
+
+size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P) {
+  if (B <= 0 || Nv <= 0 || H <= 0 || Nq <= 0 || L <= 0 || P <= 0) return 0;
+  const BinPlan p = bin_plan(B, Nv, H, Nq, L, P);
+  return p.ok ? p.bytes : 0;
+}
+
+int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* sampling_loc,
+                       const float* attn_weight, const float* grad_out, float* grad_value,
+                       float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
+                       int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream) {
+  VIDAR_ENTER();
+  return msda_bwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
+                         grad_value, grad_sampling_loc, grad_attn_weight, B, Nv, H, C, Nq, L, P, workspace,
+                         workspace_bytes, Prep{}, stream);
+}
+
+int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start_index, const float* off_raw, const float* logit_raw,
+                             const float* ref, float* loc_out, float* w_out, float* out, int bs, int Qn, int Nv,
+                             int H, int C, int Nq, int L, int P, int R, int mode, void* stream) {
+  VIDAR_ENTER();
+  if (prep_bad(bs, Qn, R, mode, L, P) || !off_raw || !logit_raw || !ref || !loc_out || !w_out)
+    return VIDAR_ERR_BAD_ARG;
+  Prep pr{};
+  pr.off_raw = off_raw; pr.logit_raw = logit_raw; pr.ref = ref; pr.loc_out = loc_out; pr.w_out = w_out;
+  pr.Qn = Qn; pr.R = R; pr.mode = mode;
+  return msda_fwd_launch(value, spatial_shapes, level_start_index, nullptr, nullptr, out, bs * Qn, Nv, H, C, Nq,
+                         L, P, pr, stream);
+}
+
+int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
+                             const int64_t* level_start_index, const float* sampling_loc,
+                             const float* attn_weight, const float* grad_out, float* grad_value,
+                             float* grad_off_raw, float* grad_logit_raw, int bs, int Qn, int Nv, int H, int C,
+                             int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream) {
+  VIDAR_ENTER();
+  if (bs < 0 || Qn <= 0 || !grad_off_raw || !grad_logit_raw) return VIDAR_ERR_BAD_ARG;
+  Prep pr{};
+  pr.g_off_raw = grad_off_raw; pr.g_logit_raw = grad_logit_raw; pr.Qn = Qn;
+  return msda_bwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
+                         grad_value, nullptr, nullptr, bs * Qn, Nv, H, C, Nq, L, P, workspace, workspace_bytes,
+                         pr, stream);
 }
 
 }  // extern "C"

@@ -110,3 +110,90 @@ def multi_scale_deformable_attn(value, spatial_shapes, level_start_index, sampli
     return MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
                                                        sampling_locations, attention_weights,
                                                        im2col_step)
+
+
+# --------------------------------------------------------------------------------------------------
+# fused operand preparation: the attention modules hand the raw outputs of their sampling_offsets /
+# attention_weights Linear layers to the op (csrc/msda.hip, vidar_msda_fused_{fwd,bwd}_f32)
+# --------------------------------------------------------------------------------------------------
+def compose_operands(off_raw, logit_raw, ref, shapes, H, Qn, L, P, mode):
+    """the reference's tensor program for (sampling_locations, attention_weights):
+    temporal_self_attention.py:218-245 / vidar_decoder.py:463-490 (mode 0: one reference point per level,
+    Qn BEV-queue entries folded into the batch) and spatial_cross_attention.py:359-383 (mode 1: point p
+    belongs to pillar anchor p % Zn).  off_raw [bs, Nq, H*Qn*L*P*2], logit_raw [bs, Nq, H*Qn*L*P],
+    ref [bs*Qn, Nq, R, 2]."""
+    bs, Nq = off_raw.shape[:2]
+    normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+    if mode == 0:
+        offsets = off_raw.view(bs, Nq, H, Qn, L, P, 2)
+        weights = logit_raw.view(bs, Nq, H, Qn, L * P).softmax(-1)
+        weights = weights.view(bs, Nq, H, Qn, L, P).permute(0, 3, 1, 2, 4, 5).reshape(bs * Qn, Nq, H, L, P).contiguous()
+        offsets = offsets.permute(0, 3, 1, 2, 4, 5, 6).reshape(bs * Qn, Nq, H, L, P, 2)
+        locations = ref[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+        return locations, weights
+    assert Qn == 1
+    Zn = ref.shape[2]
+    offsets = off_raw.view(bs, Nq, H, L, P, 2)
+    weights = logit_raw.view(bs, Nq, H, L * P).softmax(-1).view(bs, Nq, H, L, P)
+    offsets = offsets / normalizer[None, None, None, :, None, :]
+    offsets = offsets.view(bs, Nq, H, L, P // Zn, Zn, 2)
+    locations = (ref[:, :, None, None, None, :, :] + offsets).reshape(bs, Nq, H, L, P, 2)
+    return locations, weights
+
+
+class FusedDeformAttnFunction(Function):
+    """apply(value [bs*Qn,Nv,H,C], shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode) -> [bs*Qn, Nq, H*C]"""
+
+    @staticmethod
+    def forward(ctx, value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode):
+        ctx.in_dtypes = (value.dtype, off_raw.dtype, logit_raw.dtype)
+        f = lambda t: t.float().contiguous()
+        i = lambda t: t.to(device=value.device, dtype=torch.int64).contiguous()
+        value, off_raw, logit_raw, ref, shapes, lsi = f(value), f(off_raw), f(logit_raw), f(ref), i(shapes), i(lsi)
+        Bq, Nv, H, C = value.shape
+        bs, Nq = off_raw.shape[:2]
+        R = ref.shape[2]
+        if Bq != bs * Qn or ref.shape[:2] != (Bq, Nq) or off_raw.numel() != bs * Nq * H * Qn * L * P * 2 \
+                or logit_raw.numel() != bs * Nq * H * Qn * L * P:
+            raise RuntimeError("inconsistent fused MSDA operand shapes")
+        loc = torch.empty((Bq, Nq, H, L, P, 2), dtype=torch.float32, device=value.device)
+        w = torch.empty((Bq, Nq, H, L, P), dtype=torch.float32, device=value.device)
+        out = torch.empty((Bq, Nq, H * C), dtype=torch.float32, device=value.device)
+        with TIMER.span(f"msda_fwd[L={L},P={P}]", msda_fwd_bytes(Bq, Nv, H, C, Nq, L, P)):
+            check(lib().vidar_msda_fused_fwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(off_raw), ptr(logit_raw),
+                                                 ptr(ref), ptr(loc), ptr(w), ptr(out), bs, Qn, Nv, H, C, Nq, L, P,
+                                                 R, mode, stream_of(value)), "ms_deform_attn_forward (fused)")
+        ctx.save_for_backward(value, shapes, lsi, loc, w)
+        ctx.cfg = (bs, Qn, L, P, off_raw.shape, logit_raw.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        import ctypes
+        value, shapes, lsi, loc, w = ctx.saved_tensors
+        bs, Qn, L, P, off_shape, logit_shape = ctx.cfg
+        Bq, Nv, H, C = value.shape
+        Nq = loc.shape[1]
+        go = grad_output.float().contiguous()
+        gv = torch.empty_like(value)
+        g_off = torch.empty(off_shape, dtype=torch.float32, device=value.device)
+        g_logit = torch.empty(logit_shape, dtype=torch.float32, device=value.device)
+        ws, nbytes = _bwd_workspace(value, Bq, Nv, H, Nq, L, P, None)
+        with TIMER.span(f"msda_bwd[L={L},P={P}]", msda_bwd_bytes(Bq, Nv, H, C, Nq, L, P)):
+            check(lib().vidar_msda_fused_bwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w), ptr(go),
+                                                 ptr(gv), ptr(g_off), ptr(g_logit), bs, Qn, Nv, H, C, Nq, L, P,
+                                                 ptr(ws), ctypes.c_size_t(nbytes), stream_of(value)),
+                  "ms_deform_attn_backward (fused)")
+        dv, do, dl = ctx.in_dtypes
+        return gv.to(dv), None, None, g_off.to(do), g_logit.to(dl), None, None, None, None, None
+
+
+def fused_deform_attn(value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode, im2col_step=64):
+    """One entry for the three attention modules.  CUDA tensors: the fused HIP op.  Anything else (the
+    oracle-routed CPU tests) or reference points that need a gradient: the reference's tensor program followed
+    by MultiScaleDeformableAttnFunction_fp32.apply (which has no CPU implementation of its own)."""
+    if value.is_cuda and not ref.requires_grad:
+        return FusedDeformAttnFunction.apply(value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode)
+    locations, weights = compose_operands(off_raw, logit_raw, ref, shapes, value.shape[2], Qn, L, P, mode)
+    return MultiScaleDeformableAttnFunction_fp32.apply(value, shapes, lsi, locations, weights, im2col_step)

@@ -13,7 +13,7 @@ import torch.nn as nn
 from ..bricks import constant_init, xavier_init
 from ..registry import ATTENTION, build_attention
 from ._attn_common import init_deformable_offsets
-from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32
+from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32, fused_deform_attn
 
 
 def visible_query_index(bev_mask):
@@ -131,22 +131,14 @@ class MSDeformableAttention3D(nn.Module):
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         value = value.view(bs, num_value, H, -1)
-        offsets = self.sampling_offsets(query).view(bs, num_query, H, L, P, 2)
-        weights = self.attention_weights(query).view(bs, num_query, H, L * P).softmax(-1) \
-            .view(bs, num_query, H, L, P)
         if reference_points.shape[-1] != 2:
             raise ValueError("Last dim of reference_points must be 2, but get "
                              f"{reference_points.shape[-1]} instead.")
-        # each pillar anchor (num_Z_anchors of them) owns P / num_Z_anchors sampling points
-        normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
-        Zn = reference_points.shape[2]
-        assert P % Zn == 0
-        offsets = offsets / normalizer[None, None, None, :, None, :]
-        offsets = offsets.view(bs, num_query, H, L, P // Zn, Zn, 2)
-        locations = (reference_points[:, :, None, None, None, :, :] + offsets).reshape(
-            bs, num_query, H, L, P, 2)
-        out = MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
-                                                          locations, weights, self.im2col_step)
+        # each pillar anchor (num_Z_anchors of them) owns P / num_Z_anchors sampling points; the softmax, the
+        # offset normalisation and the anchor add (:359-383) happen inside the op
+        assert P % reference_points.shape[2] == 0
+        out = fused_deform_attn(value, spatial_shapes, level_start_index, self.sampling_offsets(query),
+                                self.attention_weights(query), reference_points, 1, L, P, 1, self.im2col_step)
         out = out.to(query.dtype)
         if not self.batch_first:
             out = out.permute(1, 0, 2)

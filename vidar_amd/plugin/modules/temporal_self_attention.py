@@ -9,7 +9,7 @@ import torch.nn as nn
 from ..bricks import constant_init, xavier_init
 from ..registry import ATTENTION
 from ._attn_common import init_deformable_offsets
-from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32
+from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32, fused_deform_attn
 
 
 @ATTENTION.register_module()
@@ -69,24 +69,25 @@ class TemporalSelfAttention(nn.Module):
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         value = value.reshape(bs * Qn, num_value, H, -1)
 
-        offsets = self.sampling_offsets(query).view(bs, num_query, H, Qn, L, P, 2)
-        weights = self.attention_weights(query).view(bs, num_query, H, Qn, L * P).softmax(-1)
-        weights = weights.view(bs, num_query, H, Qn, L, P).permute(0, 3, 1, 2, 4, 5) \
-            .reshape(bs * Qn, num_query, H, L, P).contiguous()
-        offsets = offsets.permute(0, 3, 1, 2, 4, 5, 6).reshape(bs * Qn, num_query, H, L, P, 2)
-
+        off_raw = self.sampling_offsets(query)
+        logit_raw = self.attention_weights(query)
         if reference_points.shape[-1] == 2:
-            normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
-            locations = reference_points[:, :, None, :, None, :] \
-                + offsets / normalizer[None, None, None, :, None, :]
+            # softmax / offset normalisation / reference add / queue permutes (:218-245) happen inside the op
+            out = fused_deform_attn(value, spatial_shapes, level_start_index, off_raw, logit_raw,
+                                    reference_points, Qn, L, P, 0, self.im2col_step)
         elif reference_points.shape[-1] == 4:
+            offsets = off_raw.view(bs, num_query, H, Qn, L, P, 2)
+            weights = logit_raw.view(bs, num_query, H, Qn, L * P).softmax(-1)
+            weights = weights.view(bs, num_query, H, Qn, L, P).permute(0, 3, 1, 2, 4, 5) \
+                .reshape(bs * Qn, num_query, H, L, P).contiguous()
+            offsets = offsets.permute(0, 3, 1, 2, 4, 5, 6).reshape(bs * Qn, num_query, H, L, P, 2)
             locations = reference_points[:, :, None, :, None, :2] \
                 + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+            out = MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
+                                                              locations, weights, self.im2col_step)
         else:
             raise ValueError("Last dim of reference_points must be 2 or 4, but get "
                              f"{reference_points.shape[-1]} instead.")
-        out = MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
-                                                          locations, weights, self.im2col_step)
         # mean over the (prev, cur) pair
         out = out.view(bs, Qn, num_query, embed_dims).mean(1).to(identity.dtype)
         out = self.output_proj(out)

@@ -13,7 +13,7 @@ from ..registry import ATTENTION, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
 from ._attn_common import init_deformable_offsets
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
 from .encoder import TransformerLayerSequence
-from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32
+from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32, fused_deform_attn
 from .ray_operations.latent_rendering import LatentRendering
 
 
@@ -141,21 +141,20 @@ class PredictionMSDeformableAttention(nn.Module):
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         value = value.view(bs, num_value, H, -1)
-        offsets = self.sampling_offsets(query).view(bs, num_query, H, L, P, 2)
-        weights = self.attention_weights(query).view(bs, num_query, H, L * P).softmax(-1) \
-            .view(bs, num_query, H, L, P)
         if reference_points.shape[-1] == 2:
-            normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
-            locations = reference_points[:, :, None, :, None, :] \
-                + offsets / normalizer[None, None, None, :, None, :]
+            out = fused_deform_attn(value, spatial_shapes, level_start_index, self.sampling_offsets(query),
+                                    self.attention_weights(query), reference_points, 1, L, P, 0, self.im2col_step)
         elif reference_points.shape[-1] == 4:
+            offsets = self.sampling_offsets(query).view(bs, num_query, H, L, P, 2)
+            weights = self.attention_weights(query).view(bs, num_query, H, L * P).softmax(-1) \
+                .view(bs, num_query, H, L, P)
             locations = reference_points[:, :, None, :, None, :2] \
                 + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+            out = MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
+                                                              locations, weights, self.im2col_step)
         else:
             raise ValueError("Last dim of reference_points must be 2 or 4, but get "
                              f"{reference_points.shape[-1]} instead.")
-        out = MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
-                                                          locations, weights, self.im2col_step)
         out = self.output_proj(out.to(identity.dtype))
         if not self.batch_first:
             out = out.permute(1, 0, 2)
