@@ -195,11 +195,22 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
  *   pc_range: HOST pointer to 6 floats, img_h/img_w: padded image shape of camera 0 (encoder.py:137-138).
  * Outputs (caller-allocated, fully written): ref_cam [F,N,B,Q,D,2] f32, bev_mask [F,N,B,Q,D] u8 (0/1),
  *   count [F,B,Q] f32 = max(1, #cameras seeing the query), idx [F,N,Q] i64 = visible queries of batch item 0
- *   in ascending order then zeros, valid [F,N,Q] u8 = slot < lens, lens [F,N] i32.
- * ------------------------------------------------------------------------- */
+ *   in ascending order, then distinct in-range filler (slot number), valid [F,N,Q] u8 = slot < lens, lens [F,N] i32.
+ *   slot_of [F,N,Q] i32 = inverse of idx (slot of a query in its camera's list, -1 = not visible).
+ * vidar_sca_rows_f32 / vidar_sca_combine_f32: the rebatch / scatter-back of SpatialCrossAttention
+ * (spatial_cross_attention.py:141-152, :164-171) and their backwards, as row gathers (csrc/bev_prep.hip):
+ *   rows   : dst [B,N,S,C] = valid[n,s] ? src[b, idx[n,s], :] (/ count[b,idx] if count) : 0;  idx/valid rows have
+ *            `stride` elements (S <= stride: a [N,S] slice of the [N,Q] tables);
+ *   combine: dst [B,Q,C]   = sum over cameras n with slot_of[n,q] in [0,S) of src[b,n,slot_of[n,q],:] (/ count[b,q]).
+ * C must be a multiple of 4. */
 int vidar_sca_plan_f32(const float* ref_3d, const float* lidar2img, float* ref_cam, uint8_t* bev_mask,
-                       float* count, int64_t* idx, uint8_t* valid, int32_t* lens, const float* pc_range,
-                       float img_h, float img_w, int F, int B, int N, int Q, int D, void* stream);
+                       float* count, int64_t* idx, uint8_t* valid, int32_t* lens, int32_t* slot_of,
+                       const float* pc_range, float img_h, float img_w, int F, int B, int N, int Q, int D,
+                       void* stream);
+int vidar_sca_rows_f32(const float* src, const int64_t* idx, const uint8_t* valid, const float* count, float* dst,
+                       int B, int N, int S, int stride, int Q, int C, void* stream);
+int vidar_sca_combine_f32(const float* src, const int32_t* slot_of, const float* count, float* dst, int B, int N,
+                          int S, int Q, int C, void* stream);
 
 /* ---------------------------------------------------------------------------
  * LatentRendering ray-march (fused).  Replaces the torch op chain of

@@ -191,7 +191,16 @@ def test_fused_operand_preparation_matches_the_reference_tensor_program(case):
     dv, do, dl = (t.cuda().requires_grad_(True) for t in (value, off_raw, logit_raw))
     out = F.fused_deform_attn(dv, sh.cuda(), lsi.cuda(), do, dl, ref.cuda(), Qn, L, P, mode)
     torch.testing.assert_close(out.detach().cpu().double(), want.detach(), rtol=1e-4, atol=2e-5)
-    got = torch.autograd.grad((out * gout.cuda()).sum(), [dv, do, dl])
+    got = [t.cpu().double() for t in torch.autograd.grad((out * gout.cuda()).sum(), [dv, do, dl])]
+    # samples within fp32 rounding of a pixel boundary: d/d offset is one-sided there (see the full-size test)
+    wh = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float64).view(1, 1, 1, L, 1, 2)
+    pixel = loc.detach() * wh - 0.5
+    kink = ((pixel - pixel.round()).abs() < 1e-4).any(-1, keepdim=True).expand_as(loc)      # [bs*Qn,Nq,H,L,P,2]
+    if mode == 0:        # back to the raw layout [bs, Nq, H, Qn, L, P, 2]
+        kink = kink.view(bs, Qn, Nq, H, L, P, 2).permute(0, 2, 3, 1, 4, 5, 6)
+    kink = kink.reshape(got[1].shape)
+    assert float(kink.double().mean()) < 0.01
+    got[1] = torch.where(kink, gwant[1], got[1])
     for a, b, nm in zip(got, gwant, ["grad_value", "grad_off_raw", "grad_logit_raw"]):
         scale = max(1.0, float(b.abs().max()))
-        torch.testing.assert_close(a.cpu().double(), b, rtol=3e-4, atol=3e-5 * scale, msg=lambda m: nm + m)
+        torch.testing.assert_close(a, b, rtol=3e-4, atol=3e-5 * scale, msg=lambda m: nm + m)

@@ -73,3 +73,38 @@ def test_encoder_pass_uses_the_plan_of_the_detector():
     finally:
         BEVFormerEncoder.plan_frames = orig
     assert calls == [5]
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_hip_rebatch_equals_the_torch_rebatch(bs):
+    """SpatialCrossAttention with the gather kernels (vidar_sca_rows / vidar_sca_combine through the inverse
+    index) against the same module on torch's advanced-index / index_add formulation: output and gradients."""
+    from vidar_amd import train as T
+    from vidar_amd.configs import get_config
+    from vidar_amd.synthetic import fpn_features, make_sample
+    torch.manual_seed(0)
+    bev = 30
+    cfg = get_config("vidar_1_8_nusc_1future", bev_h=bev, bev_w=bev)
+    enc = T.build_model(cfg).pts_bbox_head.transformer.encoder.cuda()
+    sca = enc.layers[0].attentions[1].eval()
+    samples = [make_sample(3 + b, rays_per_frame=10)[0] for b in range(bs)]
+    metas = [samples[b][2] for b in range(bs)]
+    dev = torch.device("cuda")
+    plan = enc.plan_frames([metas], bev, bev, dev)[0]
+    shapes = [(15, 25), (8, 13), (4, 7), (2, 4)]
+    Nv = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(1)
+    key = torch.randn(6, Nv, bs, 256, generator=g).cuda()
+    q0 = torch.randn(bs, bev * bev, 256, generator=g).cuda()
+    gout = torch.randn(bs, bev * bev, 256, generator=g).cuda()
+    sh = torch.tensor(shapes, device=dev); lsi = torch.cat([sh.new_zeros(1), sh.prod(1).cumsum(0)[:-1]])
+    res = []
+    for use_plan in (True, False):
+        q = q0.clone().requires_grad_(True)
+        k = key.clone().requires_grad_(True)
+        out = sca(q, k, k, reference_points_cam=plan.ref_cam, bev_mask=plan.bev_mask, spatial_shapes=sh,
+                  level_start_index=lsi, sca_index=plan.index, sca_plan=plan if use_plan else None)
+        gq, gk = torch.autograd.grad((out * gout).sum(), [q, k])
+        res.append((out.detach(), gq, gk))
+    for a, b in zip(*res):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * max(1.0, float(b.abs().max())))

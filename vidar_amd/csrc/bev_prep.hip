@@ -61,11 +61,13 @@ __global__ __launch_bounds__(256) void sca_project_kernel(
 // on entry and (slot < length) on exit
 constexpr int kCT = 1024;
 __global__ __launch_bounds__(kCT) void sca_compact_kernel(uint8_t* __restrict__ valid, int64_t* __restrict__ idx,
-                                                          int32_t* __restrict__ lens, int Q) {
+                                                          int32_t* __restrict__ lens, int32_t* __restrict__ slot_of,
+                                                          int Q) {
   __shared__ int s_wave[kCT / 64];
   __shared__ int s_base;
   uint8_t* v = valid + (int64_t)blockIdx.x * Q;
   int64_t* out = idx + (int64_t)blockIdx.x * Q;
+  int32_t* inv = slot_of + (int64_t)blockIdx.x * Q;       // query -> slot, -1 = this camera does not see it
   if (threadIdx.x == 0) s_base = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,6 +81,7 @@ __global__ __launch_bounds__(kCT) void sca_compact_kernel(uint8_t* __restrict__ 
     int before = s_base, total = 0;
     for (int w = 0; w < kCT / 64; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
     if (on) out[before + rank] = q;
+    if (q < Q) inv[q] = on ? before + rank : -1;
     __syncthreads();
     if (threadIdx.x == 0) s_base += total;
     __syncthreads();
@@ -87,17 +90,96 @@ __global__ __launch_bounds__(kCT) void sca_compact_kernel(uint8_t* __restrict__ 
   if (threadIdx.x == 0) lens[blockIdx.x] = len;
   for (int q = threadIdx.x; q < Q; q += kCT) {
     v[q] = q < len ? 1 : 0;
-    if (q >= len) out[q] = 0;          // padded slots: any in-range query (their contributions are masked)
+    if (q >= len) out[q] = q;          // padded slots: in-range and DISTINCT (their contributions are masked, but
+                                       // torch's sort-based index backward serialises over duplicate indices:
+                                       // padding with one repeated index cost 2.5 ms per SCA backward)
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SpatialCrossAttention's rebatch / scatter-back as two gathers (spatial_cross_attention.py:141-152, :164-171).
+// The reference copies the visible queries of every camera into a padded [bs, cams, max_len, C] batch with
+// python loops and adds the attention output back with a loop of indexed `+=`; in torch that is an advanced
+// index (whose backward is a sort-based index_put) and an index_add (atomics).  With the inverse map
+// slot_of[cam][query] both directions of both ops are plain row gathers:
+//   rows  : dst[b,n,s,:] = valid[n,s] ? src[b, idx[n,s], :] * (count ? 1/count[b,idx] : 1) : 0
+//   combine: dst[b,q,:]  = (sum over cameras n that see q of src[b, n, slot_of[n,q], :]) / (count ? count[b,q] : 1)
+// (rows is the forward of the rebatch and the backward of the scatter-back; combine the other two.)
+// One wave per 256-float row quarter: thread = one float4.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sca_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                                       const uint8_t* __restrict__ valid, const float* __restrict__ count,
+                                                       float* __restrict__ dst, int B, int N, int S, int stride, int Q,
+                                                       int C4) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)B * N * S * C4) return;
+  const int c = (int)(t % C4);
+  const int64_t row = t / C4;
+  const int s = (int)(row % S), n = (int)((row / S) % N), b = (int)(row / S / N);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid[(int64_t)n * stride + s]) {
+    const int64_t q = idx[(int64_t)n * stride + s];
+    v = reinterpret_cast<const float4*>(src)[((int64_t)b * Q + q) * C4 + c];
+    if (count != nullptr) {
+      const float k = count[(int64_t)b * Q + q];
+      v.x /= k; v.y /= k; v.z /= k; v.w /= k;
+    }
+  }
+  reinterpret_cast<float4*>(dst)[t] = v;
+}
+
+__global__ __launch_bounds__(256) void sca_combine_kernel(const float* __restrict__ src, const int32_t* __restrict__ slot_of,
+                                                          const float* __restrict__ count, float* __restrict__ dst,
+                                                          int B, int N, int S, int Q, int C4) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)B * Q * C4) return;
+  const int c = (int)(t % C4);
+  const int64_t row = t / C4;
+  const int q = (int)(row % Q), b = (int)(row / Q);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < N; ++n) {
+    const int s = slot_of[(int64_t)n * Q + q];
+    if (s < 0 || s >= S) continue;
+    const float4 v = reinterpret_cast<const float4*>(src)[(((int64_t)b * N + n) * S + s) * C4 + c];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (count != nullptr) {
+    const float k = count[(int64_t)b * Q + q];
+    a.x /= k; a.y /= k; a.z /= k; a.w /= k;
+  }
+  reinterpret_cast<float4*>(dst)[t] = a;
 }
 
 }  // namespace
 
 extern "C" {
 
+int vidar_sca_rows_f32(const float* src, const int64_t* idx, const uint8_t* valid, const float* count, float* dst,
+                       int B, int N, int S, int stride, int Q, int C, void* stream) {
+  VIDAR_ENTER();
+  if (B < 0 || N <= 0 || S < 0 || Q <= 0 || C <= 0 || C % 4 != 0 || stride < S) return VIDAR_ERR_BAD_ARG;
+  const int64_t n = (int64_t)B * N * S * (C / 4);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sca_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, idx,
+                     valid, count, dst, B, N, S, stride, Q, C / 4);
+  return vidar_last_error();
+}
+
+int vidar_sca_combine_f32(const float* src, const int32_t* slot_of, const float* count, float* dst, int B, int N,
+                          int S, int Q, int C, void* stream) {
+  VIDAR_ENTER();
+  if (B < 0 || N <= 0 || S < 0 || Q <= 0 || C <= 0 || C % 4 != 0) return VIDAR_ERR_BAD_ARG;
+  const int64_t n = (int64_t)B * Q * (C / 4);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sca_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     slot_of, count, dst, B, N, S, Q, C / 4);
+  return vidar_last_error();
+}
+
 int vidar_sca_plan_f32(const float* ref_3d, const float* lidar2img, float* ref_cam, uint8_t* bev_mask,
-                       float* count, int64_t* idx, uint8_t* valid, int32_t* lens, const float* pc_range,
-                       float img_h, float img_w, int F, int B, int N, int Q, int D, void* stream) {
+                       float* count, int64_t* idx, uint8_t* valid, int32_t* lens, int32_t* slot_of,
+                       const float* pc_range, float img_h, float img_w, int F, int B, int N, int Q, int D,
+                       void* stream) {
   VIDAR_ENTER();
   if (F < 0 || B <= 0 || N <= 0 || Q <= 0 || D <= 0 || !pc_range) return VIDAR_ERR_BAD_ARG;
   if (F == 0) return 0;
@@ -106,7 +188,7 @@ int vidar_sca_plan_f32(const float* ref_3d, const float* lidar2img, float* ref_c
   const int64_t n = (int64_t)F * B * Q;
   hipLaunchKernelGGL(sca_project_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      ref_3d, lidar2img, ref_cam, bev_mask, count, valid, r, img_h, img_w, F, B, N, Q, D);
-  hipLaunchKernelGGL(sca_compact_kernel, dim3(F * N), dim3(kCT), 0, (hipStream_t)stream, valid, idx, lens, Q);
+  hipLaunchKernelGGL(sca_compact_kernel, dim3(F * N), dim3(kCT), 0, (hipStream_t)stream, valid, idx, lens, slot_of, Q);
   return vidar_last_error();
 }
 

@@ -21,10 +21,12 @@ class ScaPlan:
     """What one encoder pass needs about one frame's cameras: the projected pillar anchors, their validity
     and the visible-query index of SpatialCrossAttention -- built for all frames of a step by one call of
     vidar_sca_plan_f32 (BEVFormerEncoder.plan_frames) with one host read of the list lengths."""
-    __slots__ = ("ref_cam", "bev_mask", "index")
+    __slots__ = ("ref_cam", "bev_mask", "index", "slot_of", "valid_u8", "stride", "ref_re")
 
-    def __init__(self, ref_cam, bev_mask, index):
+    def __init__(self, ref_cam, bev_mask, index, slot_of=None, valid_u8=None, stride=0):
         self.ref_cam, self.bev_mask, self.index = ref_cam, bev_mask, index
+        self.slot_of, self.valid_u8, self.stride = slot_of, valid_u8, stride     # inverse index (HIP rebatch)
+        self.ref_re = None                       # rebatched reference points, filled by the first SCA layer
 
     def __deepcopy__(self, memo):          # img_metas are deep-copied by the detector (vidar.py:286)
         return self
@@ -122,15 +124,17 @@ class BEVFormerEncoder(TransformerLayerSequence):
         idx = torch.empty((F, N, Q), device=device, dtype=torch.int64)
         valid = torch.empty((F, N, Q), device=device, dtype=torch.uint8)
         lens = torch.empty((F, N), device=device, dtype=torch.int32)
+        slot_of = torch.empty((F, N, Q), device=device, dtype=torch.int32)
         shape0 = metas_per_frame[0][0]["img_shape"][0]
         rng = (ctypes.c_float * 6)(*[float(v) for v in self.pc_range])
         check(lib().vidar_sca_plan_f32(ptr(ref_3d), ptr(l2i_d), ptr(ref_cam), ptr(mask), ptr(count), ptr(idx),
-                                       ptr(valid), ptr(lens), rng, ctypes.c_float(float(shape0[0])),
+                                       ptr(valid), ptr(lens), ptr(slot_of), rng, ctypes.c_float(float(shape0[0])),
                                        ctypes.c_float(float(shape0[1])), F, B, N, Q, D, stream_of(ref_cam)),
               "sca_plan")
         max_len = lens.max(dim=1).values.tolist()            # the one host read of the step
         return [ScaPlan(ref_cam[f], mask[f].bool(),
-                        (idx[f, :, :max_len[f]], valid[f, :, :max_len[f]].bool(), count[f]))
+                        (idx[f, :, :max_len[f]], valid[f, :, :max_len[f]].bool(), count[f]),
+                        slot_of=slot_of[f], valid_u8=valid[f], stride=Q)
                 for f in range(F)]
 
     def forward(self, bev_query, key, value, *args, bev_h=None, bev_w=None, bev_pos=None,
@@ -165,7 +169,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
                            ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
                            level_start_index=level_start_index,
                            reference_points_cam=reference_points_cam, bev_mask=bev_mask,
-                           prev_bev=prev_bev, sca_index=sca_index, **kwargs)
+                           prev_bev=prev_bev, sca_index=sca_index, sca_plan=plan, **kwargs)
             bev_query = output
             if self.latent_rendering_lid is not None:
                 if prev_bev is not None and lid in self.latent_rendering_lid:

@@ -29,6 +29,50 @@ def visible_query_index(bev_mask):
     return order, valid, count
 
 
+class _ScaRows(torch.autograd.Function):
+    """rebatch: [bs, Q, C] -> [bs, cams, max_len, C] (visible queries of every camera, zero padded);
+    backward = sum over the cameras that see a query (vidar_sca_rows_f32 / vidar_sca_combine_f32)."""
+
+    @staticmethod
+    def forward(ctx, src, plan, with_count):
+        from ..._lib import lib, check, ptr, stream_of
+        idx, valid, count = plan.index
+        bs, Q, C = src.shape
+        N, S = idx.shape
+        src = src.float().contiguous()
+        dst = torch.empty((bs, N, S, C), device=src.device)
+        check(lib().vidar_sca_rows_f32(ptr(src), ptr(idx), ptr(plan.valid_u8), ptr(count if with_count else None),
+                                       ptr(dst), bs, N, S, plan.stride, Q, C, stream_of(src)), "sca_rows")
+        ctx.plan, ctx.with_count = plan, with_count
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScaCombine.apply(g, ctx.plan, ctx.with_count), None, None
+
+
+class _ScaCombine(torch.autograd.Function):
+    """scatter-back: [bs, cams, max_len, C] -> [bs, Q, C] = sum over the cameras that see a query (/ count);
+    backward = the rebatch gather (/ count)."""
+
+    @staticmethod
+    def forward(ctx, src, plan, with_count):
+        from ..._lib import lib, check, ptr, stream_of
+        idx, valid, count = plan.index
+        bs, N, S, C = src.shape
+        Q = plan.stride
+        src = src.float().contiguous()
+        dst = torch.empty((bs, Q, C), device=src.device)
+        check(lib().vidar_sca_combine_f32(ptr(src), ptr(plan.slot_of), ptr(count if with_count else None), ptr(dst),
+                                          bs, N, S, Q, C, stream_of(src)), "sca_combine")
+        ctx.plan, ctx.with_count = plan, with_count
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        return _ScaRows.apply(g, ctx.plan, ctx.with_count), None, None
+
+
 @ATTENTION.register_module()
 class SpatialCrossAttention(nn.Module):
     def __init__(self, embed_dims=256, num_cams=6, pc_range=None, dropout=0.1, init_cfg=None,
@@ -52,7 +96,7 @@ class SpatialCrossAttention(nn.Module):
 
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
-                bev_mask=None, level_start_index=None, flag="encoder", sca_index=None, **kwargs):
+                bev_mask=None, level_start_index=None, flag="encoder", sca_index=None, sca_plan=None, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -62,6 +106,28 @@ class SpatialCrossAttention(nn.Module):
             query = query + query_pos
         bs, num_query, _ = query.size()
         D = reference_points_cam.size(3)
+        num_cams, l, bs_, embed_dims = key.shape
+        if sca_plan is not None and sca_plan.slot_of is not None and query.is_cuda and self.embed_dims % 4 == 0:
+            # HIP rebatch: both directions of the gather / scatter-back are row gathers through the inverse index
+            plan = sca_plan
+            idx, valid, count = plan.index
+            max_len = idx.shape[1]
+            if plan.ref_re is None:                       # once per frame, shared by the six layers
+                cams = torch.arange(self.num_cams, device=idx.device)
+                plan.ref_re = reference_points_cam.permute(1, 0, 2, 3, 4)[
+                    torch.arange(bs, device=idx.device)[:, None, None], cams[None, :, None], idx[None]] \
+                    * valid[None, :, :, None, None].to(query.dtype)
+            q_re = _ScaRows.apply(query, plan, False)
+            key = key.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+            value = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
+            out = self.deformable_attention(
+                query=q_re.view(bs * self.num_cams, max_len, self.embed_dims), key=key, value=value,
+                reference_points=plan.ref_re.view(bs * self.num_cams, max_len, D, 2),
+                spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+            ).view(bs, self.num_cams, max_len, self.embed_dims)
+            slots = _ScaCombine.apply(out, plan, True).to(query.dtype)      # / (#cameras seeing the query)
+            slots = self.output_proj(slots)
+            return self.dropout(slots) + inp_residual
         idx, valid, count = sca_index if sca_index is not None else visible_query_index(bev_mask)
         max_len = idx.shape[1]
         vmask = valid[None, :, :, None].to(query.dtype)
@@ -70,7 +136,6 @@ class SpatialCrossAttention(nn.Module):
         ref_re = reference_points_cam.permute(1, 0, 2, 3, 4)[torch.arange(bs, device=idx.device)[:, None, None],
                                                                 torch.arange(self.num_cams, device=idx.device)[None, :, None],
                                                                 idx[None]] * vmask[..., None]
-        num_cams, l, bs_, embed_dims = key.shape
         key = key.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
         value = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
         out = self.deformable_attention(
