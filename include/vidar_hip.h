@@ -275,7 +275,12 @@ int vidar_ray_argmax_f32(const float* sigma, const float* origin, const float* p
  * itself is a GEMM of weight [Cout, C*kh*kw] with the column matrix built here.
  *   x [N,C,H,W], offset [N,2*kh*kw,Ho,Wo] ((dy,dx) per tap), mask [N,kh*kw,Ho,Wo],
  *   cols / grad_cols [N, C*kh*kw, Ho*Wo].  deform_groups == 1.
- * col2im: grad_x zeroed by the call then accumulated with atomics; grad_offset / grad_mask written.
+ * col2im: grad_offset / grad_mask written; grad_x by one of two strategies chosen through `workspace`:
+ *   NULL  : zeroed by the call, then one fp32 atomic per (channel, tap, pixel, corner);
+ *   else  : the sampling positions are shared by all channels (deform_groups == 1), so the call sorts the
+ *           4*K*P corner entries of every image by destination pixel into the workspace
+ *           (vidar_dcn_col2im_workspace_bytes, scratch) and every destination pixel gathers its
+ *           contributions -- no atomics on grad_x, fully written.  Same result up to fp32 summation order.
  * ------------------------------------------------------------------------- */
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
                          int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
@@ -283,7 +288,8 @@ int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask,
 int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* offset,
                          const float* mask, float* grad_x, float* grad_offset, float* grad_mask,
                          int N, int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride,
-                         int pad, int dil, void* stream);
+                         int pad, int dil, void* workspace, size_t workspace_bytes, void* stream);
+size_t vidar_dcn_col2im_workspace_bytes(int N, int H, int W, int Ho, int Wo, int kh, int kw);
 
 /* Fused frozen-BatchNorm epilogue of the backbone: y = act(x*scale[c] + shift[c] (+ residual)),
  * NCHW, scale = gamma/sqrt(var+eps), shift = beta - mean*scale (BN is frozen / eval in every ViDAR

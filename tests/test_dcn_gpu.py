@@ -8,7 +8,8 @@ from oracle import dcn as D
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N,C,Cout,H,W,stride", [(2, 8, 6, 9, 11, 1), (1, 16, 16, 12, 10, 2), (1, 3, 4, 5, 5, 1)])
+@pytest.mark.parametrize("N,C,Cout,H,W,stride", [(2, 8, 6, 9, 11, 1), (1, 16, 16, 12, 10, 2), (1, 3, 4, 5, 5, 1),
+                                                 (2, 40, 8, 58, 100, 1)])      # stage-3 feature map size
 def test_dcn_fwd_bwd(N, C, Cout, H, W, stride):
     from vidar_amd.plugin.backbones import modulated_deform_conv2d
     g = torch.Generator().manual_seed(N * 100 + C)
@@ -29,6 +30,22 @@ def test_dcn_fwd_bwd(N, C, Cout, H, W, stride):
     for a, b, nm in zip(got, gref, ["x", "offset", "mask", "weight", "bias"]):
         torch.testing.assert_close(a.cpu().double(), b, rtol=2e-4, atol=2e-4 * max(1.0, float(b.abs().max())),
                                    msg=lambda m: nm + ": " + m)
+
+
+@pytest.mark.parametrize("N,C,H,W,stride", [(2, 19, 9, 11, 1), (1, 32, 29, 50, 1), (2, 5, 12, 10, 2)])
+def test_col2im_gather_equals_atomic_scatter(N, C, H, W, stride):
+    """both grad_x strategies of vidar_dcn_col2im_f32 (workspace / reverse-map gather vs atomics)"""
+    from vidar_amd.plugin.backbones import dcn_col2im
+    g = torch.Generator().manual_seed(C)
+    Ho = (H + 2 - 3) // stride + 1; Wo = (W + 2 - 3) // stride + 1
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    off = (torch.randn(N, 18, Ho, Wo, generator=g) * 2.0).cuda()
+    mask = torch.rand(N, 9, Ho, Wo, generator=g).cuda()
+    gcols = torch.randn(N, C * 9, Ho * Wo, generator=g).cuda()
+    a = dcn_col2im(gcols, x, off, mask, 3, 3, stride, 1, 1, Ho, Wo, gather=True)
+    b = dcn_col2im(gcols, x, off, mask, 3, 3, stride, 1, 1, Ho, Wo, gather=False)
+    for u, v, nm in zip(a, b, ["grad_x", "grad_offset", "grad_mask"]):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-5 * max(1.0, float(v.abs().max())), msg=lambda m: nm + m)
 
 
 def test_zero_offsets_equal_plain_convolution():

@@ -18,6 +18,25 @@ from .registry import BACKBONES, NECKS
 from .._lib import lib, check, ptr, stream_of, TIMER
 
 
+def dcn_col2im(grad_cols, x, offset, mask, kh, kw, stride, pad, dil, Ho, Wo, gather=True):
+    """gradients of the deformable column matrix w.r.t. input / offsets / mask (vidar_dcn_col2im_f32).
+    gather=True: grad_x through the per-call reverse map (no atomics); False: atomic scatter."""
+    import ctypes
+    N, C, H, W = x.shape
+    gx = torch.empty_like(x); goff = torch.empty_like(offset); gm = torch.empty_like(mask)
+    ws, nbytes = None, 0
+    if gather:
+        f = lib().vidar_dcn_col2im_workspace_bytes
+        f.restype = ctypes.c_size_t
+        nbytes = int(f(N, H, W, Ho, Wo, kh, kw))
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=x.device) if nbytes else None
+    with TIMER.span("dcn_col2im", 4 * (3 * x.numel() + 2 * offset.numel() + 2 * mask.numel() + grad_cols.numel())):
+        check(lib().vidar_dcn_col2im_f32(ptr(grad_cols), ptr(x), ptr(offset), ptr(mask), ptr(gx), ptr(goff), ptr(gm),
+                                         N, C, H, W, Ho, Wo, kh, kw, stride, pad, dil, ptr(ws),
+                                         ctypes.c_size_t(nbytes if ws is not None else 0), stream_of(x)), "dcn_col2im")
+    return gx, goff, gm
+
+
 class _ModulatedDeformConv(Function):
     @staticmethod
     def forward(ctx, x, offset, mask, weight, bias, stride, pad, dil):
@@ -48,11 +67,7 @@ class _ModulatedDeformConv(Function):
         go = grad_out.contiguous().view(N, Cout, Ho * Wo)
         grad_weight = torch.bmm(go, cols.transpose(1, 2)).sum(0).reshape(weight.shape)
         grad_cols = torch.bmm(weight.reshape(1, Cout, -1).transpose(1, 2).expand(N, -1, -1), go)
-        gx = torch.empty_like(x); goff = torch.empty_like(offset); gm = torch.empty_like(mask)
-        with TIMER.span("dcn_col2im", 4 * (3 * x.numel() + 2 * offset.numel() + 2 * mask.numel() + cols.numel())):
-            check(lib().vidar_dcn_col2im_f32(ptr(grad_cols), ptr(x), ptr(offset), ptr(mask), ptr(gx),
-                                             ptr(goff), ptr(gm), N, C, H, W, Ho, Wo, kh, kw, stride, pad,
-                                             dil, stream_of(x)), "dcn_col2im")
+        gx, goff, gm = dcn_col2im(grad_cols, x, offset, mask, kh, kw, stride, pad, dil, Ho, Wo)
         return gx, goff, gm, grad_weight, (go.sum((0, 2)) if has_bias else None), None, None, None
 
 
