@@ -151,3 +151,23 @@ def test_batch_of_two_equals_two_single_samples(name):
     bad[1][2]["prev_bev_exists"] = not bad[1][2]["prev_bev_exists"]
     with cpu_ops.patched(), torch.no_grad(), pytest.raises(ValueError):
         model(return_loss=True, img_metas=bad, gt_points=gts, img_feats=feats)
+
+
+def test_custom_ms_deformable_attention_is_registered_and_sequence_first():
+    """bevformer/modules/decoder.py:132: same op as the batch-first attention, (num_query, bs, C) tensors"""
+    from oracle import cpu_ops
+    from vidar_amd.plugin.registry import ATTENTION, build_attention
+    assert "CustomMSDeformableAttention" in ATTENTION
+    torch.manual_seed(0)
+    a = build_attention(dict(type="CustomMSDeformableAttention", embed_dims=64, num_heads=2, num_levels=2, num_points=4)).eval()
+    b = build_attention(dict(type="PredictionMSDeformableAttention", embed_dims=64, num_heads=2, num_levels=2, num_points=4)).eval()
+    b.load_state_dict(a.state_dict(), strict=True)
+    shapes = torch.tensor([[6, 5], [3, 3]]); lsi = torch.tensor([0, 30])
+    q = torch.randn(7, 2, 64); v = torch.randn(39, 2, 64); pos = torch.randn(7, 2, 64)
+    ref = torch.rand(2, 7, 2, 2)
+    with cpu_ops.patched(), torch.no_grad():
+        out_a = a(q, value=v, query_pos=pos, reference_points=ref, spatial_shapes=shapes, level_start_index=lsi)
+        out_b = b(q.permute(1, 0, 2), value=v.permute(1, 0, 2), query_pos=pos.permute(1, 0, 2), reference_points=ref,
+                  spatial_shapes=shapes, level_start_index=lsi)
+    assert out_a.shape == (7, 2, 64)
+    torch.testing.assert_close(out_a, out_b.permute(1, 0, 2), rtol=1e-5, atol=1e-6)

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void dcn_revmap_kernel(const float* __restrict
   if (!q.in) return;
   const float m = FILL ? mask[((size_t)n * K + t) * P + p] : 0.f;
   const float hh = 1.f - q.lh, hw = 1.f - q.lw;
-  int* cur = cursor + (size_t)n * HW;
-  const int src = t * P + p;
+  int* cur = cursor + ((size_t)n * K + t) * HW;      // bins are (image, tap, destination pixel): tap-major lists keep
+  const int src = t * P + p;                         // neighbouring destination pixels in step (coalesced gathers)
   auto put = [&](bool ok, int pix, float w) {
     if (!ok) return;
     if (FILL) rec[atomicAdd(cur + pix, 1)] = Entry{src, w * m};
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024) void dcn_revmap_scan_kernel(int* __restrict__
 }
 
 constexpr int kGC = 16;                        // channels per thread of the gather
-// grid: (ceil(HW/256), ceil(C/kGC), N); after the fill pass cursor[i] = end of pixel i's entries
+// grid: (ceil(HW/256), ceil(C/kGC), N); after the fill pass cursor[i] = end of bin i's entries
 __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* __restrict__ grad_cols,
                                                                 const int* __restrict__ first,
                                                                 const int* __restrict__ last,
@@ -204,23 +204,35 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* __r
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= HW) return;
   const int n = blockIdx.z, c0 = blockIdx.y * kGC;
-  const int e0 = first[(size_t)n * HW + pix], e1 = last[(size_t)n * HW + pix];
   float acc[kGC];
 #pragma unroll
   for (int c = 0; c < kGC; ++c) acc[c] = 0.f;
   const size_t KP = (size_t)K * P;
   const float* gc = grad_cols + ((size_t)n * g.C + c0) * KP;
   const int nc = min(kGC, g.C - c0);
-  if (nc == kGC) {
-    for (int e = e0; e < e1; ++e) {
-      const Entry r = rec[e];
+  for (int t = 0; t < K; ++t) {
+    const size_t bin = ((size_t)n * K + t) * HW + pix;
+    const int e0 = first[bin], e1 = last[bin];
+    if (nc == kGC) {
+      int e = e0;
+      for (; e + 1 < e1; e += 2) {               // two entries in flight: 32 independent loads per iteration
+        const Entry r0 = rec[e], r1 = rec[e + 1];
+        float v0[kGC], v1[kGC];
 #pragma unroll
-      for (int c = 0; c < kGC; ++c) acc[c] += r.w * gc[(size_t)c * KP + r.src];
-    }
-  } else {
-    for (int e = e0; e < e1; ++e) {
-      const Entry r = rec[e];
-      for (int c = 0; c < nc; ++c) acc[c] += r.w * gc[(size_t)c * KP + r.src];
+        for (int c = 0; c < kGC; ++c) { v0[c] = gc[(size_t)c * KP + r0.src]; v1[c] = gc[(size_t)c * KP + r1.src]; }
+#pragma unroll
+        for (int c = 0; c < kGC; ++c) acc[c] += r0.w * v0[c] + r1.w * v1[c];
+      }
+      if (e < e1) {
+        const Entry r = rec[e];
+#pragma unroll
+        for (int c = 0; c < kGC; ++c) acc[c] += r.w * gc[(size_t)c * KP + r.src];
+      }
+    } else {
+      for (int e = e0; e < e1; ++e) {
+        const Entry r = rec[e];
+        for (int c = 0; c < nc; ++c) acc[c] += r.w * gc[(size_t)c * KP + r.src];
+      }
     }
   }
   for (int c = 0; c < nc; ++c) grad_x[((size_t)n * g.C + c0 + c) * HW + pix] = acc[c];
@@ -287,7 +299,7 @@ int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask,
 
 size_t vidar_dcn_col2im_workspace_bytes(int N, int H, int W, int Ho, int Wo, int kh, int kw) {
   if (N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || kh <= 0 || kw <= 0) return 0;
-  const size_t hw = (size_t)N * H * W, ent = (size_t)N * kh * kw * Ho * Wo * 4;
+  const size_t hw = (size_t)N * kh * kw * H * W, ent = (size_t)N * kh * kw * Ho * Wo * 4;
   if (ent >= (1ull << 31)) return 0;
   return sizeof(int) * 2 * hw + sizeof(Entry) * ent;
 }
@@ -307,13 +319,13 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
     const size_t need = vidar_dcn_col2im_workspace_bytes(N, H, W, Ho, Wo, kh, kw);
     if (need == 0 || workspace_bytes < need) return VIDAR_ERR_BAD_ARG;
     int* cursor = (int*)workspace;
-    int* first = cursor + (size_t)N * HW;
-    Entry* rec = (Entry*)(first + (size_t)N * HW);
-    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)N * HW, s);
+    int* first = cursor + (size_t)N * K * HW;
+    Entry* rec = (Entry*)(first + (size_t)N * K * HW);
+    hipError_t e = hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)N * K * HW, s);
     if (e != hipSuccess) return (int)e;
     const dim3 rgrid((P + 255) / 256, K, N);
     hipLaunchKernelGGL(dcn_revmap_kernel<false>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
-    hipLaunchKernelGGL(dcn_revmap_scan_kernel, dim3(N), dim3(1024), 0, s, cursor, first, HW, K * P * 4);
+    hipLaunchKernelGGL(dcn_revmap_scan_kernel, dim3(N), dim3(1024), 0, s, cursor, first, K * HW, K * P * 4);
     hipLaunchKernelGGL(dcn_revmap_kernel<true>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
     hipLaunchKernelGGL(dcn_col2im_gather_kernel, dim3((HW + 255) / 256, (C + kGC - 1) / kGC, N), dim3(256), 0, s,
                        grad_cols, first, cursor, rec, grad_x, g);

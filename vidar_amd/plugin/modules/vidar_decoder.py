@@ -159,3 +159,42 @@ class PredictionMSDeformableAttention(nn.Module):
         if not self.batch_first:
             out = out.permute(1, 0, 2)
         return self.dropout(out) + identity
+
+
+@ATTENTION.register_module()
+class CustomMSDeformableAttention(PredictionMSDeformableAttention):
+    """Deformable-DETR attention of the detection decoder (bevformer/modules/decoder.py:132-345): the same op with
+    sequence-first tensors by default (`batch_first=False`) and the assertion that the key length matches the
+    level shapes.  Registered for config compatibility (fine-tuning configs); ViDAR pre-training deletes the
+    detection decoder (detectors/vidar.py:105-107)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                 batch_first=False, norm_cfg=None, init_cfg=None):
+        super().__init__(embed_dims=embed_dims, num_heads=num_heads, num_levels=num_levels, num_points=num_points,
+                         im2col_step=im2col_step, dropout=dropout, batch_first=batch_first, norm_cfg=norm_cfg,
+                         init_cfg=init_cfg)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, flag="decoder", **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+            query_pos = None
+        if not self.batch_first:                     # (num_query, bs, C) -> (bs, num_query, C)
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == value.shape[1]
+        batch_first, self.batch_first = self.batch_first, True
+        try:
+            out = super().forward(query, key, value, identity=torch.zeros_like(query), query_pos=None,
+                                  key_padding_mask=key_padding_mask, reference_points=reference_points,
+                                  spatial_shapes=spatial_shapes, level_start_index=level_start_index, **kwargs)
+        finally:
+            self.batch_first = batch_first
+        # the parent returned dropout(output_proj(attn)) + 0: add the identity in the caller's layout
+        if not self.batch_first:
+            out = out.permute(1, 0, 2)
+        return out + identity
