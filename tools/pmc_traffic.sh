@@ -3,8 +3,7 @@
 #   tools/pmc_traffic.sh <outdir> <kbench group...>
 # Writes <outdir>/pmc_{FETCH_SIZE,WRITE_SIZE}.csv reduced to "kernel,counter,value" rows.
 set -u
-out=$1; shift
-mkdir -p "$out"
+out=$(mkdir -p "$1" && cd "$1" && pwd); shift
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
