@@ -317,11 +317,20 @@ def main():
                          "avg_ms": dom["avg_ms"], "launches_per_step": dom["calls"] / args.steps,
                          "hip_ops_ms_per_step": hip_ms},
         }
-        if world == 1 and not args.no_kernel_rooflines:
+        if grouped and hasattr(ddp, "_get_ddp_logging_data"):
+            # what the gradient all-reduce moves per step (RCCL over xGMI): DDP's own bucket accounting
+            try:
+                info = ddp._get_ddp_logging_data()
+                sizes = [int(x) for x in str(info.get("bucket_sizes", "")).split(",") if x.strip()]
+                out["ddp"] = {"buckets": len(sizes), "bucket_bytes": sizes, "allreduce_bytes_per_step": sum(sizes),
+                              "bucket_cap_mb": 100, "backend": dist.get_backend(), "world_size": world}
+            except Exception as e:                                   # logging only, never fail the bench
+                out["ddp"] = {"error": str(e)[:100]}
+        if world == 1 and not args.no_kernel_rooflines and not grouped:
             del batch, ddp, opt, model
             torch.cuda.empty_cache()
             out["roofline_kernels"] = kernel_rooflines(dev)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not grouped:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
             out["cpu_baseline"]["host_cores"] = os.cpu_count()
         print(json.dumps(out), flush=True)

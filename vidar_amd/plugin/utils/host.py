@@ -16,13 +16,12 @@ class _PinnedArena:
     """One pinned staging buffer per process, bump-allocated and reused round-robin.  `tensor.pin_memory()`
     per copy is not an option: a pinned block can only be recycled once its copy has executed, the host runs
     far ahead of the GPU, so every call ends in a fresh hipHostMalloc (a slow, serialising driver call).
-    A slice is overwritten only after a full lap; the event recorded at the previous wrap-around is waited on
-    first (it completed long ago: every step reads the visible-query lengths back, which drains the stream)."""
+    A slice is overwritten only after a full lap (8 MB = a few hundred training steps of these tiny copies);
+    at the wrap-around the stream is drained once, so no copy still in flight can see its source overwritten."""
 
     def __init__(self, nbytes=8 << 20):
         self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
         self.pos = 0
-        self.lap_event = None
 
     def stage(self, src):
         """copy the CPU tensor `src` into the arena -> pinned view with src's dtype / shape"""
@@ -31,10 +30,7 @@ class _PinnedArena:
             return src.pin_memory()
         start = (self.pos + 15) & ~15
         if start + n > self.buf.numel():
-            if self.lap_event is not None:
-                self.lap_event.synchronize()
-            self.lap_event = torch.cuda.Event()
-            self.lap_event.record()
+            torch.cuda.synchronize()             # once per lap: every copy staged so far has executed
             start = 0
         self.pos = start + n
         view = self.buf[start:start + n].view(src.dtype).view(src.shape)
