@@ -188,6 +188,21 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
                              int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * y = LayerNorm(dropout(x) + residual) and its backward in one pass each (csrc/norm_fuse.hip): the tail of every
+ * attention / FFN block of the encoder and the future decoder (temporal_self_attention.py:270-271,
+ * spatial_cross_attention.py:172-174, vidar_decoder.py:515-516, mmcv FFN) followed by the layer's norm.
+ *   x, residual, y, sum_out [rows, C] f32 with C == 256; gamma, beta [C]; mean_out, rstd_out [rows].
+ *   dropout keeps element i iff hash(seed, i) >= p (recomputed in the backward from the same seed; p = 0: exact).
+ *   bwd: grad_x, grad_residual fully written; grad_gamma / grad_beta zeroed then accumulated.
+ * ------------------------------------------------------------------------- */
+int vidar_drop_add_ln_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                              float* sum_out, float* mean_out, float* rstd_out, int64_t rows, int C, float p, float eps,
+                              uint32_t seed, void* stream);
+int vidar_drop_add_ln_bwd_f32(const float* grad_y, const float* sum_in, const float* gamma, const float* mean_in,
+                              const float* rstd_in, float* grad_x, float* grad_residual, float* grad_gamma,
+                              float* grad_beta, int64_t rows, int C, float p, uint32_t seed, void* stream);
+
+/* ---------------------------------------------------------------------------
  * BEV-encoder bookkeeping for F frames at once.  Replaces BEVFormerEncoder.point_sampling
  * (projects/mmdet3d_plugin/bevformer/modules/encoder.py:96-156) and the visible-query rebatch index of
  * SpatialCrossAttention.forward (spatial_cross_attention.py:136-152, :164-171).

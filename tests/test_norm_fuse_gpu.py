@@ -1,0 +1,61 @@
+"""GPU: LayerNorm(dropout(x) + residual) fused kernels (csrc/norm_fuse.hip) against torch's three ops:
+p = 0 exactly the same function (values + all four gradients); p > 0: the kept set is a deterministic
+function of the seed, has the right rate, forward and backward use the same mask."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(rows, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, 256, generator=g).cuda().requires_grad_(True)
+    r = torch.randn(rows, 256, generator=g).cuda().requires_grad_(True)
+    norm = nn.LayerNorm(256).cuda()
+    norm.weight.data.uniform_(0.5, 1.5, generator=None); norm.bias.data.normal_()
+    gy = torch.randn(rows, 256, generator=g).cuda()
+    return x, r, norm, gy
+
+
+@pytest.mark.parametrize("rows", [1, 7, 64, 40000])
+def test_without_dropout_equals_layer_norm_of_the_sum(rows):
+    from vidar_amd.plugin.bricks import drop_add_layernorm
+    x, r, norm, gy = _setup(rows)
+    y = drop_add_layernorm(x, r, norm, 0.1, training=False)
+    ref = norm(x + r)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    a = torch.autograd.grad(y, [x, r, norm.weight, norm.bias], gy)
+    b = torch.autograd.grad(ref, [x, r, norm.weight, norm.bias], gy)
+    for u, v, nm in zip(a, b, ["x", "residual", "gamma", "beta"]):
+        torch.testing.assert_close(u, v, rtol=2e-4, atol=2e-5 * max(1.0, float(v.abs().max())), msg=lambda m: nm + m)
+
+
+def test_dropout_mask_is_consistent_between_forward_and_backward():
+    from vidar_amd.plugin import bricks
+    x, r, norm, gy = _setup(5000)
+    torch.manual_seed(7); bricks._DROP_CALLS[0] = 0
+    y = bricks.drop_add_layernorm(x.view(1, 5000, 256), r.view(1, 5000, 256), norm, 0.3, training=True).view(5000, 256)
+    gx, gr = torch.autograd.grad(y, [x, r], gy)
+    keep = gx != 0
+    rate = float(keep.float().mean())
+    assert abs(rate - 0.7) < 0.01, rate
+    ref = norm(x * keep / 0.7 + r)                     # the same kept set reproduces the forward ...
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
+    bx, br = torch.autograd.grad(ref, [x, r], gy)      # ... and the backward
+    torch.testing.assert_close(gx, bx, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(gr, br, rtol=2e-4, atol=2e-5)
+    torch.manual_seed(7); bricks._DROP_CALLS[0] = 0   # reproducible under manual_seed
+    y2 = bricks.drop_add_layernorm(x, r, norm, 0.3, training=True)
+    assert torch.equal(y2, y)
+    y3 = bricks.drop_add_layernorm(x, r, norm, 0.3, training=True)   # next call: another mask
+    assert not torch.equal(y3, y)
+
+
+def test_other_widths_take_the_torch_path():
+    from vidar_amd.plugin.bricks import can_fuse_norm, drop_add_layernorm
+    norm = nn.LayerNorm(64).cuda()
+    x = torch.randn(3, 64, device="cuda"); r = torch.randn(3, 64, device="cuda")
+    assert not can_fuse_norm(norm, x)
+    torch.testing.assert_close(drop_add_layernorm(x, r, norm, 0.5, training=False), norm(x + r))

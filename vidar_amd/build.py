@@ -31,6 +31,7 @@ PER_FILE: dict[str, list[str]] = {
     "msda.hip": ["-ffp-contract=fast"],
     "dcn.hip": ["-ffp-contract=fast"],
     "affine_act.hip": ["-ffp-contract=fast"],
+    "norm_fuse.hip": ["-ffp-contract=fast"],
 }
 
 

@@ -514,8 +514,8 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
     const int h0 = (int)floorf(y), w0 = (int)floorf(x);
     const float lh = y - h0, lw = x - w0;
-    const float wl_top = (1.f - lh) * (1.f - lw) * aw, wr_top = (1.f - lh) * lw * aw;
-    const float wl_bot = lh * (1.f - lw) * aw, wr_bot = lh * lw * aw;
+    const float w_top_l = (1.f - lh) * (1.f - lw) * aw, w_top_r = (1.f - lh) * lw * aw;
+    const float w_bot_l = lh * (1.f - lw) * aw, w_bot_r = lh * lw * aw;
     const int off = (min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1)) * kCh;
     const int gofs = (s / LP) * kCh;
     const int m = min(64, n - base);
@@ -526,18 +526,37 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         g[u] = grad_out[__builtin_amdgcn_readlane(gofs, j0 + u) + (lane & 31)];
+      // Two samples per step.  A sample's read-modify-write of its 2x2 window lines depends on the previous
+      // sample's only if their footprints touch (rows and columns both within 1): otherwise both reads are
+      // issued before either write, which halves the LDS round trips on the wave's dependency chain.
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 8; u += 2) {
         const int j = j0 + u;
+        const int oa = __builtin_amdgcn_readlane(off, j), ob = __builtin_amdgcn_readlane(off, j + 1);
         // lanes 0-31 take the left-column weights, 32-63 the right-column ones (bit select, no branch)
-        const float a_top = __int_as_float((__builtin_amdgcn_readlane(__float_as_int(wl_top), j) & ~rmask) |
-                                           (__builtin_amdgcn_readlane(__float_as_int(wr_top), j) & rmask));
-        const float a_bot = __int_as_float((__builtin_amdgcn_readlane(__float_as_int(wl_bot), j) & ~rmask) |
-                                           (__builtin_amdgcn_readlane(__float_as_int(wr_bot), j) & rmask));
-        float* p = win + __builtin_amdgcn_readlane(off, j) + lane;   // + 32 for the right column
-        const float t0 = p[0], t1 = p[kWin * kCh];
-        p[0] = t0 + a_top * g[u];
-        p[kWin * kCh] = t1 + a_bot * g[u];
+#define VIDAR_CORNER_W(V, J) __int_as_float((__builtin_amdgcn_readlane(__float_as_int(V##l), J) & ~rmask) | \
+                                            (__builtin_amdgcn_readlane(__float_as_int(V##r), J) & rmask))
+        const float a_top = VIDAR_CORNER_W(w_top_, j), a_bot = VIDAR_CORNER_W(w_bot_, j);
+        const float b_top = VIDAR_CORNER_W(w_top_, j + 1), b_bot = VIDAR_CORNER_W(w_bot_, j + 1);
+#undef VIDAR_CORNER_W
+        float* pa = win + oa + lane;                   // + 32 for the right column
+        float* pb = win + ob + lane;
+        const int la = oa / kCh, lb = ob / kCh;        // window line of the top-left corner (wave-uniform)
+        const int dr = la / kWin - lb / kWin, dc = la % kWin - lb % kWin;
+        if (dr > 1 || dr < -1 || dc > 1 || dc < -1) { // disjoint footprints
+          const float a0 = pa[0], a1 = pa[kWin * kCh], b0 = pb[0], b1 = pb[kWin * kCh];
+          pa[0] = a0 + a_top * g[u];
+          pa[kWin * kCh] = a1 + a_bot * g[u];
+          pb[0] = b0 + b_top * g[u + 1];
+          pb[kWin * kCh] = b1 + b_bot * g[u + 1];
+        } else {
+          const float a0 = pa[0], a1 = pa[kWin * kCh];
+          pa[0] = a0 + a_top * g[u];
+          pa[kWin * kCh] = a1 + a_bot * g[u];
+          const float b0 = pb[0], b1 = pb[kWin * kCh];
+          pb[0] = b0 + b_top * g[u + 1];
+          pb[kWin * kCh] = b1 + b_bot * g[u + 1];
+        }
       }
     }
   }

@@ -70,11 +70,17 @@ class FFN(nn.Module):
         self.dropout_layer = nn.Identity()
         self.add_identity = add_identity
 
-    def forward(self, x, identity=None):
+    def forward(self, x, identity=None, fuse_norm=None):
+        if fuse_norm is not None and self.add_identity and isinstance(self.layers[-1], nn.Dropout) \
+                and isinstance(self.dropout_layer, nn.Identity):
+            out = self.layers[:-1](x)                      # the closing Dropout moves into the fused tail
+            return drop_add_layernorm(out, x if identity is None else identity, fuse_norm, self.layers[-1].p,
+                                      self.training)
         out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
-        return (x if identity is None else identity) + self.dropout_layer(out)
+        res = (x if identity is None else identity) + self.dropout_layer(out)
+        return fuse_norm(res) if fuse_norm is not None else res
 
 
 @POSITIONAL_ENCODING.register_module()
@@ -121,3 +127,57 @@ def rotate_nearest(img, angle_deg, center):
     out = F.grid_sample(img.float().unsqueeze(0), grid.view(1, H, W, 2), mode="nearest",
                         padding_mode="zeros", align_corners=False)
     return out[0].to(img.dtype)
+
+
+# --------------------------------------------------------------------------------------------------
+# LayerNorm(dropout(x) + residual) as one HIP pass each way (csrc/norm_fuse.hip)
+# --------------------------------------------------------------------------------------------------
+_DROP_CALLS = [0]
+
+
+def can_fuse_norm(norm, x):
+    return (isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None and x.is_cuda
+            and x.shape[-1] == 256 and tuple(norm.normalized_shape) == (256,) and x.dtype == torch.float32)
+
+
+class _DropAddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, p, eps, seed):
+        import ctypes
+        from .._lib import lib, check, ptr, stream_of
+        x, residual = x.contiguous(), residual.contiguous()
+        rows = x.numel() // 256
+        y = torch.empty_like(x); s = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device); rstd = torch.empty(rows, device=x.device)
+        check(lib().vidar_drop_add_ln_fwd_f32(ptr(x), ptr(residual), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean),
+                                              ptr(rstd), ctypes.c_int64(rows), 256, ctypes.c_float(p),
+                                              ctypes.c_float(eps), ctypes.c_uint32(seed), stream_of(x)), "drop_add_ln_fwd")
+        ctx.save_for_backward(s, gamma, mean, rstd)
+        ctx.cfg = (p, seed, rows)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        from .._lib import lib, check, ptr, stream_of
+        s, gamma, mean, rstd = ctx.saved_tensors
+        p, seed, rows = ctx.cfg
+        gy = gy.contiguous()
+        gx = torch.empty_like(s); gres = torch.empty_like(s)
+        dgamma = torch.empty_like(gamma); dbeta = torch.empty_like(gamma)
+        check(lib().vidar_drop_add_ln_bwd_f32(ptr(gy), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(gx), ptr(gres),
+                                              ptr(dgamma), ptr(dbeta), ctypes.c_int64(rows), 256, ctypes.c_float(p),
+                                              ctypes.c_uint32(seed), stream_of(s)), "drop_add_ln_bwd")
+        return gx, gres, dgamma, dbeta, None, None, None
+
+
+def drop_add_layernorm(x, residual, norm, p, training):
+    """norm(dropout(x, p) + residual).  CUDA fp32 [.., 256] tensors with an affine nn.LayerNorm take the fused HIP
+    kernels (dropout mask = hash of (seed, element), seed drawn from torch's seeded state once per call, so a
+    manual_seed run is reproducible); everything else is the three torch ops."""
+    p = float(p) if training else 0.0
+    if can_fuse_norm(norm, x) and residual.shape == x.shape and residual.dtype == x.dtype:
+        _DROP_CALLS[0] += 1
+        seed = (torch.initial_seed() * 0x9E3779B1 + _DROP_CALLS[0] * 0x85EBCA77) & 0xFFFFFFFF
+        return _DropAddLayerNorm.apply(x, residual, norm.weight, norm.bias, p, float(norm.eps), seed)
+    return norm(F.dropout(x, p, training) + residual)

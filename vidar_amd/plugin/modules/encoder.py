@@ -10,6 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from ..bricks import can_fuse_norm
 from ..utils.host import const_tensor, to_device_async
 from ..registry import TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE, build_transformer_layer
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
@@ -223,12 +224,24 @@ class BEVFormerLayerV2(MyCustomBaseTransformerLayer):
         identity = query
         self_shapes = const_tensor([[bev_h, bev_w]], query.device, torch.int64)
         self_lsi = const_tensor([0], query.device, torch.int64)
-        for layer in self.operation_order:
+        ops = self.operation_order
+        skip = False
+        for k, layer in enumerate(ops):
+            if skip:                      # this norm was fused into the block in front of it
+                skip = False
+                continue
+            # post-norm layers: "block ; norm" = LayerNorm(dropout(block) + identity) -> one fused pass
+            fuse = None
+            if not self.pre_norm and layer in ("self_attn", "cross_attn", "ffn") and k + 1 < len(ops) \
+                    and ops[k + 1] == "norm" and can_fuse_norm(self.norms[norm_index], query):
+                fuse = self.norms[norm_index]
+                norm_index += 1
+                skip = True
             if layer == "self_attn":
                 query = self.attentions[attn_index](
                     query, prev_bev, prev_bev, identity if self.pre_norm else None, query_pos=bev_pos,
                     key_pos=bev_pos, key_padding_mask=query_key_padding_mask, reference_points=ref_2d,
-                    spatial_shapes=self_shapes, level_start_index=self_lsi, **kwargs)
+                    spatial_shapes=self_shapes, level_start_index=self_lsi, fuse_norm=fuse, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == "norm":
@@ -239,7 +252,7 @@ class BEVFormerLayerV2(MyCustomBaseTransformerLayer):
                     query, key, value, identity if self.pre_norm else None, query_pos=query_pos,
                     key_pos=key_pos, reference_points=ref_3d, reference_points_cam=reference_points_cam,
                     mask=mask, key_padding_mask=key_padding_mask, spatial_shapes=spatial_shapes,
-                    level_start_index=level_start_index, **kwargs)
+                    level_start_index=level_start_index, fuse_norm=fuse, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == "latent_render":
@@ -247,6 +260,6 @@ class BEVFormerLayerV2(MyCustomBaseTransformerLayer):
                 query = self.latent_render(query.view(bs, bev_h, bev_w, embed_dim)).view(
                     bs, token_num, embed_dim)
             elif layer == "ffn":
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None, fuse_norm=fuse)
                 ffn_index += 1
         return query

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..bricks import constant_init, xavier_init
+from ..bricks import drop_add_layernorm, constant_init, xavier_init
 from ..registry import ATTENTION, build_attention
 from ._attn_common import init_deformable_offsets
 from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32, fused_deform_attn
@@ -96,7 +96,8 @@ class SpatialCrossAttention(nn.Module):
 
     def forward(self, query, key, value, residual=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, reference_points_cam=None,
-                bev_mask=None, level_start_index=None, flag="encoder", sca_index=None, sca_plan=None, **kwargs):
+                bev_mask=None, level_start_index=None, flag="encoder", sca_index=None, sca_plan=None,
+                fuse_norm=None, **kwargs):
         if key is None:
             key = query
         if value is None:
@@ -127,6 +128,8 @@ class SpatialCrossAttention(nn.Module):
             ).view(bs, self.num_cams, max_len, self.embed_dims)
             slots = _ScaCombine.apply(out, plan, True).to(query.dtype)      # / (#cameras seeing the query)
             slots = self.output_proj(slots)
+            if fuse_norm is not None:
+                return drop_add_layernorm(slots, inp_residual, fuse_norm, self.dropout.p, self.training)
             return self.dropout(slots) + inp_residual
         idx, valid, count = sca_index if sca_index is not None else visible_query_index(bev_mask)
         max_len = idx.shape[1]
@@ -150,6 +153,8 @@ class SpatialCrossAttention(nn.Module):
             slots[j].index_add_(0, flat_idx, out[j].reshape(-1, self.embed_dims).to(slots.dtype))
         slots = slots / count[..., None]
         slots = self.output_proj(slots)
+        if fuse_norm is not None:
+            return drop_add_layernorm(slots, inp_residual, fuse_norm, self.dropout.p, self.training)
         return self.dropout(slots) + inp_residual
 
 

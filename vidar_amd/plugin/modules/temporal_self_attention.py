@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..bricks import constant_init, xavier_init
+from ..bricks import drop_add_layernorm, constant_init, xavier_init
 from ..registry import ATTENTION
 from ._attn_common import init_deformable_offsets
 from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32, fused_deform_attn
@@ -46,7 +46,7 @@ class TemporalSelfAttention(nn.Module):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, flag="decoder", **kwargs):
+                level_start_index=None, flag="decoder", fuse_norm=None, **kwargs):
         if value is None:
             assert self.batch_first
             bs, len_bev, c = query.shape
@@ -93,4 +93,6 @@ class TemporalSelfAttention(nn.Module):
         out = self.output_proj(out)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
+        if fuse_norm is not None:
+            return drop_add_layernorm(out, identity, fuse_norm, self.dropout.p, self.training)
         return self.dropout(out) + identity

@@ -8,7 +8,7 @@ import torch
 from ..utils.host import const_tensor
 import torch.nn as nn
 
-from ..bricks import constant_init, xavier_init
+from ..bricks import can_fuse_norm, drop_add_layernorm, constant_init, xavier_init
 from ..registry import ATTENTION, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
 from ._attn_common import init_deformable_offsets
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
@@ -69,13 +69,24 @@ class PredictionTransformerLayer(MyCustomBaseTransformerLayer):
         cross_shapes = const_tensor([[bev_h, bev_w]] * num_frames, dev, torch.int64)
         cross_lsi = torch.cat((cross_shapes.new_zeros((1,)), cross_shapes.prod(1).cumsum(0)[:-1]))
         prev_feats = prev_feats.reshape(bs, num_frames * prev_tokens, prev_dims)
-        for layer in self.operation_order:
+        ops = self.operation_order
+        skip = False
+        for k, layer in enumerate(ops):
+            if skip:                      # this norm was fused into the block in front of it
+                skip = False
+                continue
+            fuse = None
+            if not self.pre_norm and layer in ("self_attn", "cross_attn", "ffn") and k + 1 < len(ops) \
+                    and ops[k + 1] == "norm" and can_fuse_norm(self.norms[norm_index], query):
+                fuse = self.norms[norm_index]
+                norm_index += 1
+                skip = True
             if layer == "self_attn":
                 query = self.attentions[attn_index](
                     query, None, None, identity if self.pre_norm else None, query_pos=bev_pos,
                     key_pos=bev_pos, key_padding_mask=query_key_padding_mask,
                     reference_points=tgt_points, spatial_shapes=self_shapes,
-                    level_start_index=self_lsi, **kwargs)
+                    level_start_index=self_lsi, fuse_norm=fuse, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == "norm":
@@ -85,14 +96,14 @@ class PredictionTransformerLayer(MyCustomBaseTransformerLayer):
                 query = self.attentions[attn_index](
                     query, prev_feats, prev_feats, identity if self.pre_norm else None,
                     query_pos=bev_pos, reference_points=ref_points, key_padding_mask=key_padding_mask,
-                    spatial_shapes=cross_shapes, level_start_index=cross_lsi, **kwargs)
+                    spatial_shapes=cross_shapes, level_start_index=cross_lsi, fuse_norm=fuse, **kwargs)
                 attn_index += 1
                 identity = query
             elif layer == "latent_render":
                 b, n, c = query.shape
                 query = self.latent_render(query.view(b, bev_h, bev_w, c)).view(b, n, c)
             elif layer == "ffn":
-                query = self.ffns[ffn_index](query, identity if self.pre_norm else None)
+                query = self.ffns[ffn_index](query, identity if self.pre_norm else None, fuse_norm=fuse)
                 ffn_index += 1
         return query
 
@@ -127,7 +138,7 @@ class PredictionMSDeformableAttention(nn.Module):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, flag="decoder", **kwargs):
+                level_start_index=None, flag="decoder", fuse_norm=None, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -158,6 +169,8 @@ class PredictionMSDeformableAttention(nn.Module):
         out = self.output_proj(out.to(identity.dtype))
         if not self.batch_first:
             out = out.permute(1, 0, 2)
+        if fuse_norm is not None:
+            return drop_add_layernorm(out, identity, fuse_norm, self.dropout.p, self.training)
         return self.dropout(out) + identity
 
 
