@@ -193,14 +193,17 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
  * spatial_cross_attention.py:172-174, vidar_decoder.py:515-516, mmcv FFN) followed by the layer's norm.
  *   x, residual, y, sum_out [rows, C] f32 with C == 256; gamma, beta [C]; mean_out, rstd_out [rows].
  *   dropout keeps element i iff hash(seed, i) >= p (recomputed in the backward from the same seed; p = 0: exact).
- *   bwd: grad_x, grad_residual fully written; grad_gamma / grad_beta zeroed then accumulated.
+ *   bwd: grad_x, grad_residual fully written; grad_gamma / grad_beta zeroed then accumulated from per-workgroup
+ *   partial rows kept in `workspace` (vidar_drop_add_ln_bwd_workspace_bytes, scratch).
  * ------------------------------------------------------------------------- */
 int vidar_drop_add_ln_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                               float* sum_out, float* mean_out, float* rstd_out, int64_t rows, int C, float p, float eps,
                               uint32_t seed, void* stream);
 int vidar_drop_add_ln_bwd_f32(const float* grad_y, const float* sum_in, const float* gamma, const float* mean_in,
                               const float* rstd_in, float* grad_x, float* grad_residual, float* grad_gamma,
-                              float* grad_beta, int64_t rows, int C, float p, uint32_t seed, void* stream);
+                              float* grad_beta, void* workspace, int64_t rows, int C, float p, uint32_t seed,
+                              void* stream);
+size_t vidar_drop_add_ln_bwd_workspace_bytes(int64_t rows); /* scratch for the per-workgroup affine-gradient partials */
 
 /* ---------------------------------------------------------------------------
  * BEV-encoder bookkeeping for F frames at once.  Replaces BEVFormerEncoder.point_sampling

@@ -167,6 +167,25 @@ def bench_dcn(which):
                    4 * (3 * x.numel() + gcols.numel() + 2 * off.numel() + 2 * mask.numel()))
 
 
+def bench_norm(which):
+    """LayerNorm(dropout(x) + residual) on a [40000, 256] BEV map: fused HIP kernels vs torch's three ops."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from vidar_amd.plugin.bricks import drop_add_layernorm
+    norm = nn.LayerNorm(256).cuda()
+    x = torch.randn(1, 40000, 256, device="cuda", requires_grad=True)
+    r = torch.randn(1, 40000, 256, device="cuda", requires_grad=True)
+    gy = torch.randn(1, 40000, 256, device="cuda")
+    nb = x.numel() * 4
+    for name, fn in (("fused", lambda: drop_add_layernorm(x, r, norm, 0.1, True)),
+                     ("torch", lambda: norm(F.dropout(x, 0.1, True) + r))):
+        ms = timeit(lambda: fn())
+        report(f"drop_add_ln fwd {name}", ms, 3 * nb)
+        y = fn()
+        ms = timeit(lambda: torch.autograd.grad(y, [x, r, norm.weight, norm.bias], gy, retain_graph=True))
+        report(f"drop_add_ln bwd {name}", ms, 4 * nb)
+
+
 def bench_lr(which):
     from vidar_amd.plugin.modules.ray_operations.latent_rendering import _PathProb, _RayGather
     for step in (1.0, 0.5):

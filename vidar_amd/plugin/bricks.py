@@ -165,8 +165,11 @@ class _DropAddLayerNorm(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(s); gres = torch.empty_like(s)
         dgamma = torch.empty_like(gamma); dbeta = torch.empty_like(gamma)
+        f = lib().vidar_drop_add_ln_bwd_workspace_bytes
+        f.restype = ctypes.c_size_t
+        ws = torch.empty((int(f(ctypes.c_int64(rows))) + 3) // 4, device=s.device)
         check(lib().vidar_drop_add_ln_bwd_f32(ptr(gy), ptr(s), ptr(gamma), ptr(mean), ptr(rstd), ptr(gx), ptr(gres),
-                                              ptr(dgamma), ptr(dbeta), ctypes.c_int64(rows), 256, ctypes.c_float(p),
+                                              ptr(dgamma), ptr(dbeta), ptr(ws), ctypes.c_int64(rows), 256, ctypes.c_float(p),
                                               ctypes.c_uint32(seed), stream_of(s)), "drop_add_ln_bwd")
         return gx, gres, dgamma, dbeta, None, None, None
 
