@@ -83,14 +83,6 @@ def cpu_baseline(config, threads, with_backbone=True, reduced=True):
     from vidar_amd.configs import get_config
     from vidar_amd.synthetic import fpn_features, make_sample
     torch.set_num_threads(threads)
-    # never drive the host out of memory: cap this child's address space at half of the host RAM
-    try:
-        import resource
-        total = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
-        cap = min(total // 2, (48 << 30) if reduced else (1 << 40))
-        resource.setrlimit(resource.RLIMIT_AS, (cap, cap))
-    except (ImportError, ValueError, OSError):
-        pass
     div = 4 if reduced else 1
     cfg = get_config(config, bev_h=200 // div, bev_w=200 // div, with_backbone=with_backbone)
     torch.manual_seed(0); np.random.seed(0)
@@ -232,6 +224,14 @@ def kernel_rooflines(dev):
 def main():
     args = parse()
     if args.cpu_baseline_only:
+        # never drive the host out of memory: cap this child's address space (a full-size CPU step took a box down)
+        try:
+            import resource
+            total = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+            cap = min(total // 2, (1 << 40) if args.cpu_baseline_full else (48 << 30))
+            resource.setrlimit(resource.RLIMIT_AS, (cap, cap))
+        except (ImportError, ValueError, OSError):
+            pass
         print(json.dumps(cpu_baseline(args.config, args.cpu_threads, not args.no_backbone,
                                       reduced=not args.cpu_baseline_full)), flush=True)
         return
