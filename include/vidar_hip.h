@@ -193,7 +193,7 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
  * spatial_cross_attention.py:172-174, vidar_decoder.py:515-516, mmcv FFN) followed by the layer's norm.
  *   x, residual, y, sum_out [rows, C] f32 with C == 256; gamma, beta [C]; mean_out, rstd_out [rows].
  *   dropout keeps element i iff hash(seed, i) >= p (recomputed in the backward from the same seed; p = 0: exact).
- *   bwd: grad_x, grad_residual fully written; grad_gamma / grad_beta zeroed then accumulated from per-workgroup
+ *   bwd: grad_x, grad_residual, grad_gamma, grad_beta fully written (the affine gradients from per-workgroup
  *   partial rows kept in `workspace` (vidar_drop_add_ln_bwd_workspace_bytes, scratch).
  * ------------------------------------------------------------------------- */
 int vidar_drop_add_ln_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,

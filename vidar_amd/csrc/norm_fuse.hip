@@ -127,18 +127,29 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(
   }
 }
 
-// second stage: grid (kSlices) x 512 threads; thread = one of the 2*256 affine-gradient columns, sums a slice of
-// the per-workgroup partial rows and adds it to the (zeroed) result with one atomic
-constexpr int kSlices = 16;
-__global__ __launch_bounds__(512) void affine_grad_reduce_kernel(const float* __restrict__ partial, int nparts,
+// second stage: block = 32 of the 2*256 affine-gradient columns x 8 row lanes; every thread sums every 8th partial
+// row of its column, the 8 lanes meet in LDS, the result is WRITTEN (no zeroing, no atomics)
+__global__ __launch_bounds__(256) void affine_grad_reduce_kernel(const float* __restrict__ partial, int nparts,
                                                                  float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta) {
-  const int col = threadIdx.x;
-  const int per = (nparts + kSlices - 1) / kSlices;
-  const int p0 = blockIdx.x * per, p1 = min(nparts, p0 + per);
-  float acc = 0.f;
-  for (int i = p0; i < p1; ++i) acc += partial[(size_t)i * 2 * kC + col];
-  if (p0 < p1) unsafeAtomicAdd(col < kC ? dgamma + col : dbeta + (col - kC), acc);
+  __shared__ float s_acc[8][32];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;                       // 0 .. 2*kC-1
+  float a0 = 0.f, a1 = 0.f;
+  int i = r;
+  for (; i + 8 < nparts; i += 16) {
+    a0 += partial[(size_t)i * 2 * kC + col];
+    a1 += partial[(size_t)(i + 8) * 2 * kC + col];
+  }
+  if (i < nparts) a0 += partial[(size_t)i * 2 * kC + col];
+  s_acc[r][c] = a0 + a1;
+  __syncthreads();
+  if (r == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += s_acc[k][c];
+    if (col < kC) dgamma[col] = t; else dbeta[col - kC] = t;
+  }
 }
 
 }  // namespace
@@ -169,16 +180,17 @@ int vidar_drop_add_ln_bwd_f32(const float* grad_y, const float* sum_in, const fl
   VIDAR_ENTER();
   if (rows < 0 || C != kC || p < 0.f || p >= 1.f) return VIDAR_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_gamma, 0, sizeof(float) * kC, s);
-  if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, sizeof(float) * kC, s);
-  if (e != hipSuccess) return (int)e;
-  if (rows == 0) return 0;
+  if (rows == 0) {
+    hipError_t e = hipMemsetAsync(grad_gamma, 0, sizeof(float) * kC, s);
+    if (e == hipSuccess) e = hipMemsetAsync(grad_beta, 0, sizeof(float) * kC, s);
+    return (int)e;
+  }
   if (!workspace) return VIDAR_ERR_BAD_ARG;
   const int64_t waves = (rows + kRowsPerWave - 1) / kRowsPerWave;
   const int nparts = (int)((waves + 3) / 4);
   hipLaunchKernelGGL(drop_add_ln_bwd_kernel, dim3((unsigned)nparts), dim3(256), 0, s, grad_y, sum_in, gamma, mean_in,
                      rstd_in, grad_x, grad_residual, (float*)workspace, rows, p, seed);
-  hipLaunchKernelGGL(affine_grad_reduce_kernel, dim3(kSlices), dim3(512), 0, s, (const float*)workspace, nparts,
+  hipLaunchKernelGGL(affine_grad_reduce_kernel, dim3(2 * kC / 32), dim3(256), 0, s, (const float*)workspace, nparts,
                      grad_gamma, grad_beta);
   return vidar_last_error();
 }
