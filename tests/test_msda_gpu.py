@@ -204,3 +204,34 @@ def test_fused_operand_preparation_matches_the_reference_tensor_program(case):
     for a, b, nm in zip(got, gwant, ["grad_value", "grad_off_raw", "grad_logit_raw"]):
         scale = max(1.0, float(b.abs().max()))
         torch.testing.assert_close(a, b, rtol=3e-4, atol=3e-5 * scale, msg=lambda m: nm + m)
+
+
+@pytest.mark.parametrize("scatter", list(SCATTER))
+def test_samples_outside_the_level_and_nan_locations_contribute_nothing(scatter):
+    """every sample off the level (or NaN): zero output, zero gradients, nothing binned -- both strategies"""
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    shapes = [(10, 12), (5, 6)]
+    value, sh, loc, w = M.make_case(2, 2, shapes, 300, P=4)
+    loc = loc + 5.0                                   # far outside [0, 1]
+    loc[0, :7] = float("nan")
+    lsi = M.level_start_index(shapes).cuda()
+    out = F._msda_forward(value.cuda(), sh.cuda(), lsi, loc.cuda(), w.cuda())
+    assert float(out.abs().max()) == 0.0
+    gv, gl, gw = F._msda_backward(value.cuda(), sh.cuda(), lsi, loc.cuda(), w.cuda(),
+                                  torch.randn(2, 300, 256, device="cuda"), binned=SCATTER[scatter])
+    assert float(gv.abs().max()) == 0.0 and float(gl.abs().max()) == 0.0 and float(gw.abs().max()) == 0.0
+
+
+def test_one_hot_destination_pixel_many_chunks():
+    """all 40 000 x 8 x 4 samples land on the same 2x2 pixels: one destination tile, > 1000 chunks flushing onto
+    the same window lines (the binned path's worst case) still equals the atomic scatter"""
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    shapes = [(16, 16)]
+    value, sh, loc, w = M.make_case(3, 1, shapes, 40000, P=4)
+    loc = torch.full_like(loc, 0.5) + (torch.rand(loc.shape, generator=torch.Generator().manual_seed(1)) - 0.5) * 0.05
+    lsi = M.level_start_index(shapes).cuda()
+    go = torch.randn(1, 40000, 256, generator=torch.Generator().manual_seed(2)).cuda()
+    a = F._msda_backward(value.cuda(), sh.cuda(), lsi, loc.cuda(), w.cuda(), go, binned=True)
+    b = F._msda_backward(value.cuda(), sh.cuda(), lsi, loc.cuda(), w.cuda(), go, binned=False)
+    for u, v in zip(a, b):
+        torch.testing.assert_close(u, v, rtol=2e-3, atol=2e-3 * max(1.0, float(v.abs().max())))

@@ -108,3 +108,27 @@ def test_hip_rebatch_equals_the_torch_rebatch(bs):
         res.append((out.detach(), gq, gk))
     for a, b in zip(*res):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * max(1.0, float(b.abs().max())))
+
+
+def test_no_camera_sees_anything():
+    """all cameras looking away from the BEV plane (every anchor behind them): empty visible lists, the encoder
+    pass still runs and SpatialCrossAttention contributes only its residual path"""
+    from test_plugin_cpu import _small_batch
+    from vidar_amd import train as T
+    torch.manual_seed(0); np.random.seed(0)
+    cfg, batch = _small_batch("vidar_1_8_nusc_1future")
+    for m in batch["img_metas"][0].values():
+        flip = np.diag([1.0, 1.0, -1.0, 1.0])
+        m["lidar2img"] = [np.asarray(a) @ np.diag([1.0, 1.0, 1.0, 1.0]) * 0 + np.array(
+            [[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 0, -50.0], [0, 0, 0, 1.0]]) for a in m["lidar2img"]]
+    model = T.build_model(cfg).cuda().train()
+    enc = model.pts_bbox_head.transformer.encoder
+    frames = [[batch["img_metas"][0][t]] for t in range(5)]
+    plans = enc.plan_frames(frames, 24, 24, torch.device("cuda"))
+    assert all(p.index[0].shape[1] == 0 and not bool(p.bev_mask.any()) for p in plans)
+    assert all(float(p.index[2].min()) == 1.0 for p in plans)                 # count clamps to 1
+    losses = model(return_loss=True, img_metas=batch["img_metas"], gt_points=[g.cuda() for g in batch["gt_points"]],
+                   img_feats=[f.cuda() for f in batch["img_feats"]])
+    total = sum(losses.values())
+    total.backward()
+    assert torch.isfinite(total)

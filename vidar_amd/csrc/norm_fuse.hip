@@ -67,7 +67,12 @@ constexpr int kRowsPerWave = 4;
 __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(
     const float* __restrict__ gout, const float* __restrict__ sum_in, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, float* __restrict__ gx,
-    float* __restrict__ gres, float* __restrict__ partial, int64_t rows, float p, uint32_t seed) {
+    float* __restrict__ gres, float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int64_t rows, float p, uint32_t seed) {
+  if (blockIdx.x == 0) {                      // zero the second stage's accumulators (it runs after this kernel)
+    dgamma[threadIdx.x] = 0.f;
+    dbeta[threadIdx.x] = 0.f;
+  }
   const int lane = threadIdx.x & 63;
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kRowsPerWave;
   const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
@@ -127,28 +132,32 @@ __global__ __launch_bounds__(256) void drop_add_ln_bwd_kernel(
   }
 }
 
-// second stage: block = 32 of the 2*256 affine-gradient columns x 8 row lanes; every thread sums every 8th partial
-// row of its column, the 8 lanes meet in LDS, the result is WRITTEN (no zeroing, no atomics)
+// second stage: grid (16 column blocks, kSlices row slices); block = 32 of the 2*256 affine-gradient columns x 8 row
+// lanes.  Every thread sums its share of the partial rows, the 8 lanes meet in LDS, one atomic per (block, column)
+// onto the result -- which workgroup 0 of the first stage zeroed (stream order makes that safe, no memset launch).
+constexpr int kSlices = 8;
 __global__ __launch_bounds__(256) void affine_grad_reduce_kernel(const float* __restrict__ partial, int nparts,
                                                                  float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta) {
   __shared__ float s_acc[8][32];
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c;                       // 0 .. 2*kC-1
+  const int per = (nparts + kSlices - 1) / kSlices;
+  const int p0 = blockIdx.y * per, p1 = min(nparts, p0 + per);
   float a0 = 0.f, a1 = 0.f;
-  int i = r;
-  for (; i + 8 < nparts; i += 16) {
+  int i = p0 + r;
+  for (; i + 8 < p1; i += 16) {
     a0 += partial[(size_t)i * 2 * kC + col];
     a1 += partial[(size_t)(i + 8) * 2 * kC + col];
   }
-  if (i < nparts) a0 += partial[(size_t)i * 2 * kC + col];
+  if (i < p1) a0 += partial[(size_t)i * 2 * kC + col];
   s_acc[r][c] = a0 + a1;
   __syncthreads();
-  if (r == 0) {
+  if (r == 0 && p0 < p1) {
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += s_acc[k][c];
-    if (col < kC) dgamma[col] = t; else dbeta[col - kC] = t;
+    unsafeAtomicAdd(col < kC ? dgamma + col : dbeta + (col - kC), t);
   }
 }
 
@@ -189,8 +198,8 @@ int vidar_drop_add_ln_bwd_f32(const float* grad_y, const float* sum_in, const fl
   const int64_t waves = (rows + kRowsPerWave - 1) / kRowsPerWave;
   const int nparts = (int)((waves + 3) / 4);
   hipLaunchKernelGGL(drop_add_ln_bwd_kernel, dim3((unsigned)nparts), dim3(256), 0, s, grad_y, sum_in, gamma, mean_in,
-                     rstd_in, grad_x, grad_residual, (float*)workspace, rows, p, seed);
-  hipLaunchKernelGGL(affine_grad_reduce_kernel, dim3(2 * kC / 32), dim3(256), 0, s, (const float*)workspace, nparts,
+                     rstd_in, grad_x, grad_residual, (float*)workspace, grad_gamma, grad_beta, rows, p, seed);
+  hipLaunchKernelGGL(affine_grad_reduce_kernel, dim3(2 * kC / 32, kSlices), dim3(256), 0, s, (const float*)workspace, nparts,
                      grad_gamma, grad_beta);
   return vidar_last_error();
 }
