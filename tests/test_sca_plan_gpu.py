@@ -117,10 +117,10 @@ def test_no_camera_sees_anything():
     from vidar_amd import train as T
     torch.manual_seed(0); np.random.seed(0)
     cfg, batch = _small_batch("vidar_1_8_nusc_1future")
-    for m in batch["img_metas"][0].values():
-        flip = np.diag([1.0, 1.0, -1.0, 1.0])
-        m["lidar2img"] = [np.asarray(a) @ np.diag([1.0, 1.0, 1.0, 1.0]) * 0 + np.array(
-            [[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 0, -50.0], [0, 0, 0, 1.0]]) for a in m["lidar2img"]]
+    metas = batch["img_metas"][0]
+    for m in (metas.values() if isinstance(metas, dict) else metas):
+        # depth = -50 for every anchor: cz <= eps, nothing is valid
+        m["lidar2img"] = [np.array([[1.0, 0, 0, 0], [0, 1.0, 0, 0], [0, 0, 0, -50.0], [0, 0, 0, 1.0]]) for _ in m["lidar2img"]]
     model = T.build_model(cfg).cuda().train()
     enc = model.pts_bbox_head.transformer.encoder
     frames = [[batch["img_metas"][0][t]] for t in range(5)]
