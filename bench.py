@@ -202,18 +202,12 @@ def kernel_rooflines(dev):
         add(f"dvr.render[M={M}]", hip_time(lambda: dvr.render(sigma, origin, points, tindex, "l1")),
             2 * vol + N * M * 24 + cnt * 12, bound="fp64 issue + per-lane atomics, not HBM")
         del out, em
-    g = torch.Generator().manual_seed(0)
+    from vidar_amd.synthetic import msda_operands
     fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
     for name, B, shapes, Nq, P in (("TSA", 2, [(200, 200)], 40000, 4), ("SCA", 6, fpn, 10000, 8)):
-        L = len(shapes); Nv = sum(h * w for h, w in shapes)
-        value = torch.randn(B, Nv, 8, 32, generator=g).to(dev)
-        ref = torch.rand(B, Nq, 1, 1, 1, 2, generator=g) * 1.2 - 0.1
-        loc = (ref + (torch.rand(B, Nq, 8, L, P, 2, generator=g) * 2 - 1) * 0.05).clamp(-0.1, 1.1).to(dev)
-        w = torch.softmax(torch.randn(B, Nq, 8, L * P, generator=g), -1).view(B, Nq, 8, L, P).to(dev)
-        sh = torch.tensor(shapes, dtype=torch.int64, device=dev)
-        sizes = torch.tensor([h * w for h, w in shapes])
-        lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]]).to(dev)
-        go = torch.randn(B, Nq, 256, generator=g).to(dev)
+        value, sh, lsi, loc, w = msda_operands(0, B, shapes, Nq, P=P, device=dev)
+        L = len(shapes); Nv = value.shape[1]
+        go = torch.randn(B, Nq, 256, device=dev)
         add(f"msda_fwd[{name}]", hip_time(lambda: _msda_forward(value, sh, lsi, loc, w)),
             msda_fwd_bytes(B, Nv, 8, 32, Nq, L, P), bound="L1/TA line rate (61 M corner lines), reported vs HBM")
         add(f"msda_bwd[{name}]", hip_time(lambda: _msda_backward(value, sh, lsi, loc, w, go)),

@@ -49,3 +49,14 @@ def test_product_never_imports_oracle():
     for f in (ROOT / "vidar_amd" / "csrc").glob("*"):
         if f.is_file() and f.suffix in (".hip", ".h"):
             assert "oracle" not in f.read_text().lower(), f
+    # tools/ (benchmarks, profiling helpers) must not lean on the checker either, directly or through tests/
+    for f in (ROOT / "tools").rglob("*.py"):
+        src = f.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, f
+        assert "from test_" not in src and "import test_" not in src, f
+    # bench.py: only the cpu_baseline leg
+    lines = (ROOT / "bench.py").read_text().splitlines()
+    uses = [i for i, l in enumerate(lines) if "from oracle" in l or "import oracle" in l]
+    start = next(i for i, l in enumerate(lines) if l.startswith("def cpu_baseline("))
+    end = next(i for i, l in enumerate(lines) if i > start and l.startswith("def "))
+    assert uses and all(start < i < end for i in uses), uses

@@ -99,13 +99,13 @@ def bench_msda_coherent(which):
     """both scatter strategies of msda_bwd on spatially coherent queries (what the model produces:
     neighbouring BEV queries sample next to each other; the random reference points of `bench_msda`
     share no lines) + their agreement."""
-    from oracle import msda as M   # operand generator only (bench tool, not product)
+    from vidar_amd.synthetic import msda_operands
     from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_backward
     fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
     for name, B, shapes, Nq, P, px in (("TSA-like", 2, [(200, 200)], 40000, 4, 1.0),
                                        ("SCA-like far (2 level-0 px between queries)", 6, fpn, 10000, 8, 2.0),
                                        ("SCA-like near (8 px)", 6, fpn, 10000, 8, 8.0)):
-        value, sh, loc, w = M.make_case(0, B, shapes, Nq, P=P)
+        value, sh, lsi, loc, w = msda_operands(0, B, shapes, Nq, P=P)
         L = len(shapes)
         side = int(Nq ** 0.5)
         q = torch.arange(Nq)
@@ -114,8 +114,7 @@ def bench_msda_coherent(which):
         g = torch.Generator().manual_seed(1)
         off = (torch.rand(1, 1, 8, L, P, 2, generator=g) - 0.5) * 0.02      # per (head, level, point), shared by queries
         loc = (base[None, :, None, None, None, :] + off).expand(B, Nq, 8, L, P, 2).contiguous().clamp(0.0, 0.999)
-        value, sh, loc, w = value.cuda(), sh.cuda(), loc.cuda(), w.cuda()
-        lsi = M.level_start_index(shapes).cuda()
+        value, sh, lsi, loc, w = value.cuda(), sh.cuda(), lsi.cuda(), loc.cuda(), w.cuda()
         go = torch.randn(B, Nq, 256, device="cuda")
         outs = {}
         for binned in (False, True):
@@ -128,14 +127,12 @@ def bench_msda_coherent(which):
 
 
 def bench_msda(which):
-    from oracle import msda as M   # operand generator only (bench tool, not product)
+    from vidar_amd.synthetic import msda_operands
     from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_forward, _msda_backward
     fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
     for name, B, shapes, Nq, P in (("TSA", 2, [(200, 200)], 40000, 4), ("SCA", 6, fpn, 10000, 8),
                                    ("Pred", 1, [(200, 200)], 40000, 4)):
-        value, sh, loc, w = M.make_case(0, B, shapes, Nq, P=P)
-        value, sh, loc, w = value.cuda(), sh.cuda(), loc.cuda(), w.cuda()
-        lsi = M.level_start_index(shapes).cuda()
+        value, sh, lsi, loc, w = msda_operands(0, B, shapes, Nq, P=P, device="cuda")
         L = len(shapes); Nv = value.shape[1]
         fwd_bytes = 4 * (B * Nv * 256 + B * Nq * 8 * L * P * 3 + B * Nq * 256)
         ms = timeit(lambda: _msda_forward(value, sh, lsi, loc, w))
@@ -218,8 +215,7 @@ def bench_ray(which):
     g = torch.ones_like(ce)
     ms = timeit(lambda: torch.autograd.grad(ce, sigma, g, retain_graph=True))
     report("ray_ce_bwd P=30000", ms, 4 * (2 * 16 * 200 * 200 + 30000 * 5))
-    sys.path.insert(0, str(ROOT / 'tests'))
-    from test_ray_ops_gpu import dense_rays
+    from vidar_amd.synthetic import dense_rays
     pts, tix = dense_rays(1, 16, 200, 200, "cuda")
     noise = gumbel_noise(pts.shape[0], 512)
     ms = timeit(lambda: ray_gumbel(sigma, o, pts, tix, noise))

@@ -141,3 +141,34 @@ def fpn_features(seed, T, num_cams=6, channels=256, shapes=FPN_SHAPES_NUSC, devi
     import torch
     g = torch.Generator(device="cpu").manual_seed(seed)
     return [torch.randn(bs, T, num_cams, channels, h, w, generator=g).to(device) for h, w in shapes]
+
+
+def msda_operands(seed, B, shapes, Nq, H=8, C=32, P=4, spread=0.05, device="cpu"):
+    """Synthetic operands of the deformable-attention op at a given shape: value ~ N(0,1), sampling
+    locations = a random reference point per query +- U(-spread, spread) clipped to [-0.1, 1.1] (exercises the zero
+    padding), softmaxed weights.  -> value [B,Nv,H,C], shapes [L,2] i64, level_start_index [L] i64,
+    loc [B,Nq,H,L,P,2], w [B,Nq,H,L,P]."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    L = len(shapes)
+    Nv = sum(int(h) * int(w) for h, w in shapes)
+    value = torch.randn(B, Nv, H, C, generator=g)
+    ref = torch.rand(B, Nq, 1, 1, 1, 2, generator=g) * 1.2 - 0.1
+    loc = (ref + (torch.rand(B, Nq, H, L, P, 2, generator=g) * 2 - 1) * spread).clamp(-0.1, 1.1).contiguous()
+    w = torch.softmax(torch.randn(B, Nq, H, L * P, generator=g), -1).view(B, Nq, H, L, P).contiguous()
+    sh = torch.tensor(shapes, dtype=torch.int64)
+    sizes = torch.tensor([int(h) * int(w_) for h, w_ in shapes])
+    lsi = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)[:-1]])
+    return tuple(t.to(device) for t in (value, sh, lsi, loc, w))
+
+
+def dense_rays(Fn, Z, Y, X, device="cpu"):
+    """end points of the dense-loss rays: the voxel centres of a (Y/4, X/4, Z/4) sub-grid per frame
+    (dense_heads/vidar_head_base.py:606-630) -> (pts [Fn*n, 3] in voxel units, frame index [Fn*n])"""
+    import torch
+    from .plugin.utils.e2e_predictor_utils import get_bev_grids_3d
+    v = get_bev_grids_3d(Y // 4, X // 4, Z // 4, bs=1, device=device)
+    v = (v * v.new_tensor([X, Y, Z])).view(-1, 3)
+    pts = torch.cat([v for _ in range(Fn)], 0)
+    tix = torch.cat([torch.full((v.shape[0],), float(f), device=device) for f in range(Fn)], 0)
+    return pts, tix
