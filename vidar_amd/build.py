@@ -49,7 +49,7 @@ def _stamp(src: Path, flags: list[str]) -> str:
 
 
 def _compile(src: Path, verbose: bool) -> Path:
-    flags = COMMON + PER_FILE.get(src.name, [])
+    flags = COMMON + PER_FILE.get(src.name, []) + os.environ.get("VIDAR_EXTRA_HIPCC_FLAGS", "").split()
     obj = OBJ / (src.stem + ".o")
     stamp = OBJ / (src.stem + ".stamp")
     want = _stamp(src, flags)

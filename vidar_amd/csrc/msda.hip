@@ -375,9 +375,15 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
 constexpr int kTile = 8;                       // tile edge (top-left corner pixels)
 constexpr int kWin = kTile + 1;                // window edge (corner pixels)
 constexpr int kWinLines = kWin * kWin;         // 81 lines of 32 floats
-constexpr int kChunk = 1024;                   // samples per wave
+#ifndef VIDAR_MSDA_CHUNK
+#define VIDAR_MSDA_CHUNK 1024
+#endif
+#ifndef VIDAR_MSDA_TWAVES
+#define VIDAR_MSDA_TWAVES 2
+#endif
+constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per wave (tuning sweep: tools/tune_msda_tile.sh)
 constexpr int kMaxL = 16;                      // levels supported by the binned path
-constexpr int kTWaves = 2;                     // waves (= chunks) per workgroup of the tile kernel
+constexpr int kTWaves = VIDAR_MSDA_TWAVES;     // waves (= chunks) per workgroup of the tile kernel
 
 struct LevelTab {
   int Hl[kMaxL], Wl[kMaxL], ntx[kMaxL], toff[kMaxL];
