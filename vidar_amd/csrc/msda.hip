@@ -799,8 +799,9 @@ int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
                              const float* ref, float* loc_out, float* w_out, float* out, int bs, int Qn, int Nv,
                              int H, int C, int Nq, int L, int P, int R, int mode, void* stream) {
   VIDAR_ENTER();
-  if (prep_bad(bs, Qn, R, mode, L, P) || !off_raw || !logit_raw || !ref || !loc_out || !w_out)
-    return VIDAR_ERR_BAD_ARG;
+  if (prep_bad(bs, Qn, R, mode, L, P)) return VIDAR_ERR_BAD_ARG;
+  if ((int64_t)bs * Qn * Nq * H == 0) return msda_bad(bs * Qn, Nv, H, C, Nq, L, P) ? VIDAR_ERR_BAD_ARG : 0;
+  if (!off_raw || !logit_raw || !ref || !loc_out || !w_out) return VIDAR_ERR_BAD_ARG;   // (empty tensors are NULL)
   Prep pr{};
   pr.off_raw = off_raw; pr.logit_raw = logit_raw; pr.ref = ref; pr.loc_out = loc_out; pr.w_out = w_out;
   pr.Qn = Qn; pr.R = R; pr.mode = mode;
@@ -814,7 +815,8 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
                              float* grad_off_raw, float* grad_logit_raw, int bs, int Qn, int Nv, int H, int C,
                              int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
-  if (bs < 0 || Qn <= 0 || !grad_off_raw || !grad_logit_raw) return VIDAR_ERR_BAD_ARG;
+  if (bs < 0 || Qn <= 0) return VIDAR_ERR_BAD_ARG;
+  if ((int64_t)bs * Qn * Nq * H != 0 && (!grad_off_raw || !grad_logit_raw)) return VIDAR_ERR_BAD_ARG;
   Prep pr{};
   pr.g_off_raw = grad_off_raw; pr.g_logit_raw = grad_logit_raw; pr.Qn = Qn;
   return msda_bwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
