@@ -421,7 +421,7 @@ __device__ __forceinline__ int sample_tile(const LevelTab& t, const float* __res
 // counters once per (workgroup, touched tile).
 constexpr int kBinQ = 512;                     // queries per workgroup
 constexpr int kBinSamples = 16;                // samples per thread held in registers (fill pass)
-constexpr int kMaxTilesLds = 8192;             // LDS histogram capacity (tiles of one level)
+constexpr int kMaxTilesLds = 8000;             // LDS histogram capacity: 2 x 4 B x 8000 + the level table < 64 KB
 
 template <bool FILL>
 __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
