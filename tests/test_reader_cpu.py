@@ -133,3 +133,58 @@ def test_model_consumes_a_read_sample(tmp_path):
     with cpu_ops.patched():
         losses = model(return_loss=True, img_metas=[s["img_metas"]], gt_points=[s["gt_points"]], img_feats=feats)
     assert all(torch.isfinite(v) for v in losses.values()) and len(losses) == 10
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 5])
+def test_crop_resize_flip_matches_reference_class(seed):
+    """CropResizeFlipImage against the reference's own class (tests/golden/make_augment_golden.py): same draws,
+    the second frame of a queue replays the first frame's parameters, cam2img / lidar2img follow the image"""
+    import copy
+    import random
+    from make_augment_golden import CONF, inputs
+    from vidar_amd.data.augment import CropResizeFlipImage
+    gold = np.load(GOLD / "augment.npz")
+    random.seed(seed); np.random.seed(seed)
+    aug = CropResizeFlipImage(CONF, training=True)
+    aug_param = {}
+    for frame in range(2):
+        imgs, cam2img, lidar2cam = inputs(seed * 10 + frame)
+        meta = dict(cam2img=copy.deepcopy(cam2img), lidar2cam=copy.deepcopy(lidar2cam))
+        out = aug([i.copy() for i in imgs], meta, aug_param)
+        np.testing.assert_array_equal(np.stack(out), gold[f"s{seed}_f{frame}_img"])
+        np.testing.assert_allclose(np.stack(meta["cam2img"]), gold[f"s{seed}_f{frame}_cam2img"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.stack(meta["lidar2img"]), gold[f"s{seed}_f{frame}_lidar2img"], rtol=0, atol=1e-12)
+    p = aug_param["CropResizeFlipImage_param"]
+    np.testing.assert_allclose([p[0], p[1][0], p[1][1], float(p[3])], gold[f"s{seed}_param"])
+
+
+def test_hsv_round_trip_and_photometric_draw_order():
+    """[3P, unpinned] the restated BGR<->HSV pair is an exact inverse on float images; the distortion consumes numpy's
+    generator in the reference's order (8 binary draws + their uniforms) and leaves shape / dtype alone"""
+    from vidar_amd.data.augment import PhotoMetricDistortionMultiViewImage, bgr2hsv, hsv2bgr
+    img = np.random.default_rng(0).uniform(0, 255, (20, 30, 3)).astype(np.float32)
+    np.testing.assert_allclose(hsv2bgr(bgr2hsv(img)), img, rtol=0, atol=2e-3)
+    hsv = bgr2hsv(np.array([[[0.0, 0.0, 255.0], [255.0, 0.0, 0.0], [10.0, 10.0, 10.0]]], np.float32))   # red, blue, grey
+    np.testing.assert_allclose(hsv[0, :, 0], [0.0, 240.0, 0.0], atol=1e-4)
+    np.testing.assert_allclose(hsv[0, :, 1], [1.0, 1.0, 0.0], atol=1e-6)
+    np.random.seed(3)
+    out = PhotoMetricDistortionMultiViewImage()([img.copy(), img.copy()])
+    assert len(out) == 2 and out[0].shape == img.shape and out[0].dtype == np.float32
+    assert not np.allclose(out[0], out[1])                 # every image draws its own distortion (the loop is per image)
+
+
+def test_training_reader_applies_one_augmentation_to_the_whole_queue(tmp_path):
+    import random
+    from vidar_amd.data.reader import TrainAugment, ViDARSequenceDataset
+    ann = _mini_nuscenes(tmp_path)
+    conf = {"reisze": [24, 32], "crop": (0, 0, 64, 40), "H": 40, "W": 64, "rand_flip": True}
+    ds = ViDARSequenceDataset(ann, queue_length=2, future_length=1, augment=TrainAugment(conf, photometric=False))
+    random.seed(1); np.random.seed(1)
+    s = ds[3]
+    params = [s["img_metas"][t]["aug_param"]["CropResizeFlipImage_param"] for t in range(3)]
+    assert params[0] == params[1] == params[2]
+    resize, dims = params[0][0], params[0][1]
+    assert s["img"].shape[-2:] == ((dims[1] + 31) // 32 * 32, (dims[0] + 31) // 32 * 32)
+    k = s["img_metas"][2]["cam2img"][0]
+    np.testing.assert_allclose(k[0, 0], 50.0 * resize)     # focal length follows the resize
+    np.testing.assert_allclose(s["img_metas"][2]["lidar2img"][0], k @ s["img_metas"][2]["lidar2cam"][0])

@@ -11,8 +11,8 @@ nuscenes_vidar_dataset_v1.py:38-203; config :279-330), restated as plain functio
                         (first point of every occupied voxel, in order of first appearance)         [3P mmdet3d]
   load_images           LoadMultiViewImageFromFiles(to_float32) + NormalizeMultiviewImage +
                         PadMultiViewImage(size_divisor=32) (pipelines/transform_3d.py:8-95)         [3P mmcv imread]
-Not restated: PhotoMetricDistortionMultiViewImage / CropResizeFlipImage (host-side image augmentation of the
-training pipeline, config :308-311) -- `ViDARSequenceDataset(augment=...)` takes a callable for them.
+  TrainAugment          PhotoMetricDistortionMultiViewImage + CropResizeFlipImage of the training pipeline
+                        (config :308-311; vidar_amd/data/augment.py), enabled with `ViDARSequenceDataset(augment=True)`
 [3P] pieces follow the published behaviour of mmcv 1.4.0 / mmdet3d 0.17.1 (not vendored by the reference)."""
 from __future__ import annotations
 
@@ -112,17 +112,25 @@ def voxel_subsample(points: np.ndarray, voxel_size=(1.0, 1.0, 1.0), point_cloud_
     return points[keep]
 
 
-def load_images(paths: Sequence, mean=IMG_NORM["mean"], std=IMG_NORM["std"], to_rgb=IMG_NORM["to_rgb"],
-                size_divisor: int = 32):
-    """-> (float32 [cams, 3, H_pad, W_pad], padded shape (H, W, 3)).  Channel order BGR like mmcv.imread
-    (cv2); `to_rgb` flips it before normalising like mmcv.imnormalize; zero padding at bottom / right."""
+def load_raw_images(paths: Sequence) -> list:
+    """-> list of float32 [H, W, 3] arrays, channel order BGR like mmcv.imread (cv2), values 0..255
+    (LoadMultiViewImageFromFiles(to_float32=True))"""
     from PIL import Image
-    imgs = []
+    out = []
     for p in paths:
         if str(p).endswith(".npy"):
-            a = np.load(p).astype(np.float32)                        # already BGR float (test fixtures)
+            out.append(np.load(p).astype(np.float32))               # already BGR float (test fixtures)
         else:
-            a = np.asarray(Image.open(p).convert("RGB"), dtype=np.float32)[..., ::-1]
+            out.append(np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"), dtype=np.float32)[..., ::-1]))
+    return out
+
+
+def normalise_pad(imgs: Sequence, mean=IMG_NORM["mean"], std=IMG_NORM["std"], to_rgb=IMG_NORM["to_rgb"],
+                  size_divisor: int = 32):
+    """NormalizeMultiviewImage + PadMultiViewImage(size_divisor) -> (float32 [cams, 3, H_pad, W_pad], padded shape);
+    `to_rgb` flips the channels before normalising like mmcv.imnormalize; zero padding at bottom / right."""
+    out = []
+    for a in imgs:
         if to_rgb:
             a = a[..., ::-1]
         a = (a - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
@@ -131,9 +139,30 @@ def load_images(paths: Sequence, mean=IMG_NORM["mean"], std=IMG_NORM["std"], to_
         W = (w + size_divisor - 1) // size_divisor * size_divisor
         pad = np.zeros((H, W, 3), np.float32)
         pad[:h, :w] = a
-        imgs.append(pad)
-    arr = np.stack(imgs)                                             # [cams, H, W, 3]
+        out.append(pad)
+    arr = np.stack(out)                                              # [cams, H, W, 3]
     return torch.from_numpy(np.ascontiguousarray(arr.transpose(0, 3, 1, 2))), tuple(arr.shape[1:])
+
+
+def load_images(paths: Sequence, mean=IMG_NORM["mean"], std=IMG_NORM["std"], to_rgb=IMG_NORM["to_rgb"],
+                size_divisor: int = 32):
+    """load + normalise + pad (the test pipeline, config :319-330)"""
+    return normalise_pad(load_raw_images(paths), mean, std, to_rgb, size_divisor)
+
+
+class TrainAugment:
+    """PhotoMetricDistortionMultiViewImage then CropResizeFlipImage (config :308-311), `aug_param` carried from
+    frame to frame of a queue so that every frame of a sample gets the same crop / resize / flip."""
+
+    def __init__(self, data_aug_conf=None, photometric=True):
+        from .augment import CropResizeFlipImage, PhotoMetricDistortionMultiViewImage
+        self.photo = PhotoMetricDistortionMultiViewImage() if photometric else None
+        self.crop = CropResizeFlipImage(data_aug_conf, training=True)
+
+    def __call__(self, imgs, meta, aug_param):
+        if self.photo is not None:
+            imgs = self.photo(imgs)
+        return self.crop(imgs, meta, aug_param)
 
 
 class ViDARSequenceDataset:
@@ -144,15 +173,15 @@ class ViDARSequenceDataset:
     def __init__(self, ann_file, data_root="", queue_length=4, future_length=1, test_mode=False,
                  load_interval=1, load_frame_interval=None, rand_frame_interval=(1,),
                  ego_mask=(-0.8, -1.5, 0.8, 2.5), sweeps_num=2, voxel_size=(1.0, 1.0, 1.0),
-                 point_cloud_range=PC_RANGE, max_voxels=50000, dataset="nuscenes",
-                 augment: Optional[Callable] = None):
+                 point_cloud_range=PC_RANGE, max_voxels=50000, dataset="nuscenes", augment=None):
         self.infos, self.metadata = load_infos(ann_file, load_interval)
         self.data_root, self.dataset = str(data_root), dataset
         self.queue_length, self.future_length, self.test_mode = queue_length, future_length, test_mode
         self.rand_frame_interval, self.ego_mask = tuple(rand_frame_interval), ego_mask
         self.sweeps_num, self.voxel_size = sweeps_num, voxel_size
         self.point_cloud_range, self.max_voxels = point_cloud_range, max_voxels
-        self.augment = augment
+        # True: the released training augmentation; a callable (imgs, meta, aug_param) -> imgs; None: none
+        self.augment = TrainAugment() if augment is True else augment
         self.usable_index = usable_indices(self.infos, future_length, queue_length, test_mode, load_frame_interval)
 
     def __len__(self):
@@ -161,8 +190,8 @@ class ViDARSequenceDataset:
     def _path(self, p):
         return str(Path(self.data_root) / p) if self.data_root and not Path(p).is_absolute() else str(p)
 
-    def frame(self, index, with_images=True):
-        """one frame through the pipeline -> record dict(img, points, img_metas)"""
+    def frame(self, index, with_images=True, aug_param=None):
+        """one frame through the pipeline -> record dict(img, points, img_metas[, aug_param])"""
         meta = frame_meta_from_info(copy.deepcopy(self.infos[index]), self.dataset, self.data_root)
         pts = load_points_file(self._path(meta["pts_filename"]))
         if not self.test_mode:                                       # train pipeline: sweeps + voxel subsample
@@ -171,18 +200,25 @@ class ViDARSequenceDataset:
             pts = voxel_subsample(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
         rec = dict(points=torch.from_numpy(np.ascontiguousarray(pts)), img_metas=meta)
         if with_images:
-            img, shape = load_images([self._path(p) for p in meta["img_filename"]])
+            imgs = load_raw_images([self._path(p) for p in meta["img_filename"]])
+            if self.augment is not None and not self.test_mode:
+                aug_param = {} if aug_param is None else aug_param
+                imgs = self.augment(imgs, meta, aug_param)
+                rec["aug_param"] = aug_param
+            img, shape = normalise_pad(imgs)
             n = img.shape[0]
             meta.update(img_shape=[shape] * n, pad_shape=[shape] * n, img_norm_cfg=dict(IMG_NORM))
             rec["img"] = img
-            if self.augment is not None:
-                rec = self.augment(rec)
         return rec
 
     def __getitem__(self, i):
         index = self.usable_index[i]
         interval = int(np.random.choice(self.rand_frame_interval, 1)[0])
         prev, fut = frame_index_lists(index, self.queue_length, self.future_length, interval, len(self.infos))
-        previous_queue = [self.frame(k) for k in prev]
+        previous_queue, aug_param = [], None
+        for k in prev:                       # the first frame draws the augmentation, the others replay it (:116-124)
+            rec = self.frame(k, aug_param=aug_param)
+            aug_param = copy.deepcopy(rec["aug_param"]) if "aug_param" in rec else None
+            previous_queue.append(rec)
         future_queue = [self.frame(k, with_images=False) for k in fut]
         return union2one(previous_queue, future_queue, self.future_length, self.ego_mask)
