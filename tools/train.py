@@ -5,8 +5,8 @@
         /path/to/released/config.py --iters 1000 --cfg-options model.supervise_all_future=False
 
 CONFIG is one of the in-repo names (vidar_amd.configs.VARIANTS) or a path to a released mmcv-style
-config file, which loads unchanged.  Data: the synthetic generator (no dataset code in scope);
-every rank draws its own samples.  DDP over RCCL, AdamW + cosine/warm-up, grad-clip 35, JSON-lines
+config file, which loads unchanged.  Data: the synthetic generator (every rank draws its own samples), or with
+--ann-file an info pkl read by vidar_amd.data (multi-sweep lidar, image augmentation, DistributedGroupSampler).  DDP over RCCL, AdamW + cosine/warm-up, grad-clip 35, JSON-lines
 log, mmcv-layout checkpoints, --resume-from."""
 import argparse
 import ast
@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--samples", type=int, default=4, help="distinct synthetic samples cycled per rank")
     ap.add_argument("--cfg-options", nargs="*", default=[], help="dotted overrides a.b=c")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ann-file", help="nuScenes / OpenScene info pkl (data/nuscenes/nuscenes_infos_temporal_train.pkl)")
+    ap.add_argument("--data-root", default="")
+    ap.add_argument("--workers", type=int, default=4)
     args = ap.parse_args()
 
     from vidar_amd import checkpoint as C
@@ -85,7 +88,26 @@ def main():
     work = Path(args.work_dir)
     if rank == 0:
         work.mkdir(parents=True, exist_ok=True)
-    n = T.fit(ddp, opt, [sample(i) for i in range(args.samples)], args.iters, scheduler=sched, max_norm=clip,
+    if args.ann_file:                      # real data: reader -> rank-sharded sampler -> collate -> device
+        from vidar_amd.data import ViDARSequenceDataset
+        from vidar_amd.data.loader import build_dataloader
+        ds = ViDARSequenceDataset(args.ann_file, data_root=args.data_root, queue_length=meta["queue_length"],
+                                  future_length=meta["future_frames"], augment=True,
+                                  dataset="nuplan" if "OpenScene" in meta["name"] else "nuscenes")
+        loader = build_dataloader(ds, 1, args.workers, world, rank, args.seed)
+
+        class _Epochs:                      # fit() re-iterates `batches` until --iters: one pass = one epoch
+            epoch = 0
+
+            def __iter__(self):
+                loader.sampler.set_epoch(self.epoch); self.epoch += 1
+                for b in loader:
+                    yield dict(img=b["img"].to(dev, non_blocking=True), img_metas=b["img_metas"],
+                               gt_points=[g.to(dev, non_blocking=True) for g in b["gt_points"]])
+        batches = _Epochs()
+    else:
+        batches = [sample(i) for i in range(args.samples)]
+    n = T.fit(ddp, opt, batches, args.iters, scheduler=sched, max_norm=clip,
               log_every=10, log_path=work / "log.jsonl", ckpt_path=work / "latest.pth",
               ckpt_every=max(1, args.iters // 2), rank=rank, start_iter=it0)
     if rank == 0:

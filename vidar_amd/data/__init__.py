@@ -6,3 +6,4 @@ from .assemble import (frame_index_lists, frame_meta_from_info, transform_matrix
 from .augment import CropResizeFlipImage, PhotoMetricDistortionMultiViewImage  # noqa: F401
 from .reader import (TrainAugment, ViDARSequenceDataset, load_images, load_infos, load_multi_sweeps, load_points_file,  # noqa: F401
                      voxel_subsample)
+from .loader import DistributedGroupSampler, DistributedSampler, build_dataloader, collate  # noqa: F401
