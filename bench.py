@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-kernel-rooflines", action="store_true",
                     help="skip the per-kernel roofline list (dvr family + MSDA at BASELINE shapes)")
     ap.add_argument("--op-table", action="store_true", help="print the per-op timing table to stderr")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="leave the library GEMMs on their default heuristics (A/B of vidar_amd/gemm_tuning.py)")
+    ap.add_argument("--tunableop-file", help="where TunableOp writes the solutions it found (default /tmp/...)")
     return ap.parse_args()
 
 
@@ -240,6 +243,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = get_config(args.config, with_backbone=not args.no_backbone)
+    from vidar_amd import gemm_tuning
+    tuning = dict(enabled=False) if args.no_gemm_tuning else gemm_tuning.enable(results_file=args.tunableop_file, rank=rank)
     torch.manual_seed(1234)                      # identical initial weights on every rank
     np.random.seed(1000 + rank)
     model = T.build_model(cfg).to(dev).train()
@@ -315,6 +320,7 @@ def main():
                          "traffic": pmc_traffic(dom_name)[0], "traffic_source": pmc_traffic(dom_name)[1],
                          "avg_ms": dom["avg_ms"], "launches_per_step": dom["calls"] / args.steps,
                          "ms_per_step": dom["total_ms"] / args.steps, "hip_ops_ms_per_step": hip_ms},
+            "gemm_tuning": dict(tuning, solutions=gemm_tuning.count_results() if tuning.get("enabled") else 0),
             "roofline_step_dominant": {"bound": "hbm", "kernel": all_name, "achieved": all_ach, "peak": HBM_PEAK_GBPS,
                                        "unit": "GB/s", "frac": all_ach / HBM_PEAK_GBPS, "avg_ms": all_dom["avg_ms"],
                                        "launches_per_step": all_dom["calls"] / args.steps,

@@ -61,6 +61,8 @@ def main():
         clip = cfg.optimizer_config.grad_clip.max_norm
         if args.no_backbone:
             model_cfg.pop("img_backbone", None); model_cfg.pop("img_neck", None)
+    from vidar_amd import gemm_tuning
+    gemm_tuning.enable(rank=rank)               # tuned library-GEMM solutions (vidar_amd/gemm_tuning.py)
     torch.manual_seed(args.seed); np.random.seed(args.seed + rank)
     model = T.build_model(model_cfg).to(dev).train()
     ddp = T.wrap_ddp(model, local)

@@ -133,6 +133,9 @@ class BEVFormerEncoder(TransformerLayerSequence):
                                        ctypes.c_float(float(shape0[1])), F, B, N, Q, D, stream_of(ref_cam)),
               "sca_plan")
         max_len = lens.max(dim=1).values.tolist()            # the one host read of the step
+        # round the padded length up to a multiple of 256: the GEMMs of the cross attention then see a small set
+        # of shapes (tuned once, stable allocator blocks) for <= 3 % more masked slots
+        max_len = [min(Q, (m + 255) // 256 * 256) if m > 0 else 0 for m in max_len]
         return [ScaPlan(ref_cam[f], mask[f].bool(),
                         (idx[f, :, :max_len[f]], valid[f, :, :max_len[f]].bool(), count[f]),
                         slot_of=slot_of[f], valid_u8=valid[f], stride=Q)
