@@ -76,3 +76,23 @@ def test_fused_frozen_bn_epilogue(shape, res):
     b = torch.autograd.grad(ref, leaves, g)
     for u, v in zip(a, b):
         torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("stride,bias", [(1, False), (2, False), (1, True)])
+def test_conv1x1_as_batched_gemm_equals_conv2d(stride, bias):
+    """backbones.Conv1x1 (1x1 convolutions of the ResNet bottlenecks as torch GEMMs) against F.conv2d"""
+    import torch.nn.functional as F
+    from vidar_amd.plugin.backbones import Conv1x1
+    torch.manual_seed(0)
+    m = Conv1x1(24, 40, 1, stride=stride, bias=bias).cuda()
+    x = torch.randn(3, 24, 17, 22, device="cuda", requires_grad=True)
+    y = m(x)
+    ref = F.conv2d(x, m.weight, m.bias, stride=stride)
+    torch.testing.assert_close(y, ref, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(ref)
+    params = [x, m.weight] + ([m.bias] if bias else [])
+    a = torch.autograd.grad(y, params, g, retain_graph=True)
+    b = torch.autograd.grad(ref, params, g)
+    for u, v in zip(a, b):
+        torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4 * max(1.0, float(v.abs().max())))
+    assert sorted(m.state_dict()) == (["bias", "weight"] if bias else ["weight"]) and m.weight.shape == (40, 24, 1, 1)

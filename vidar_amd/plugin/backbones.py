@@ -7,6 +7,7 @@ gfx950 kernel pair of csrc/dcn.hip and the deformable convolution itself is a hi
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -166,13 +167,32 @@ class FrozenBN(nn.BatchNorm2d):
         return _AffineAct.apply(x, scale, shift, residual, relu)
 
 
+class Conv1x1(nn.Conv2d):
+    """1x1 convolution as a batched GEMM  out[n] = W [Cout, Cin] x[n] [Cin, H*W]  on NCHW tensors.  Same parameter
+    names / shapes as nn.Conv2d (`weight` [Cout, Cin, 1, 1]); two thirds of ResNet101's convolutions are 1x1, and as
+    torch GEMMs they go through the tuned library solutions of vidar_amd/gemm_tuning.py instead of MIOpen's default
+    rocBLAS pick.  A stride > 1 subsamples the input first (what a strided 1x1 convolution computes)."""
+    as_gemm = os.environ.get("VIDAR_CONV1X1_GEMM", "1") != "0"
+
+    def forward(self, x):
+        if not (self.as_gemm and x.is_cuda and self.kernel_size == (1, 1) and self.padding == (0, 0) and self.groups == 1):
+            return super().forward(x)
+        if self.stride != (1, 1):
+            x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous()
+        N, C, H, W = x.shape
+        out = torch.bmm(self.weight.view(1, self.out_channels, C).expand(N, -1, -1), x.reshape(N, C, H * W))
+        if self.bias is not None:
+            out = out + self.bias.view(1, -1, 1)
+        return out.view(N, self.out_channels, H, W)
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, style="caffe", dcn=None, bn_grad=False):
         super().__init__()
         s1, s2 = (stride, 1) if style == "caffe" else (1, stride)
-        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.conv1 = Conv1x1(inplanes, planes, 1, stride=s1, bias=False)
         self.bn1 = FrozenBN(planes, bn_grad)
         if dcn is not None:
             self.conv2 = ModulatedDeformConv2dPack(planes, planes, 3, stride=s2, padding=1, dilation=1,
@@ -180,7 +200,7 @@ class Bottleneck(nn.Module):
         else:
             self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
         self.bn2 = FrozenBN(planes, bn_grad)
-        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.conv3 = Conv1x1(planes, planes * 4, 1, bias=False)
         self.bn3 = FrozenBN(planes * 4, bn_grad)
         self.downsample = downsample
 
@@ -213,7 +233,7 @@ class ResNet(nn.Module):
             stage_dcn = dcn if stage_with_dcn[i] else None
             down = None
             if strides[i] != 1 or inplanes != planes * 4:
-                down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=strides[i], bias=False),
+                down = nn.Sequential(Conv1x1(inplanes, planes * 4, 1, stride=strides[i], bias=False),
                                      FrozenBN(planes * 4, bn_grad))
             blocks = [Bottleneck(inplanes, planes, strides[i], down, style, stage_dcn, bn_grad)]
             inplanes = planes * 4
