@@ -55,3 +55,16 @@ def test_cpu_baseline_leg_reports_a_bounded_sample():
     assert rec["kind"] == "port" and rec["unit"] == "samples/s" and rec["cores"] == 4
     assert rec["value"] > 0 and "bounded sample" in rec["sample"] and "x that" in rec["sample"]
     json.dumps(rec)
+
+
+def test_gemm_tuning_is_a_no_op_without_a_gpu_and_ships_validated_solutions():
+    from vidar_amd import gemm_tuning
+    if not torch.cuda.is_available():
+        assert gemm_tuning.enable() == dict(enabled=False, reason="no GPU")
+    lines = gemm_tuning.SHIPPED.read_text().splitlines()
+    validators = [l for l in lines if l.startswith("Validator,")]
+    entries = [l.split(",") for l in lines if l and not l.startswith("Validator,")]
+    assert {v.split(",")[1] for v in validators} >= {"PT_VERSION", "GCN_ARCH_NAME", "ROCBLAS_VERSION", "HIPBLASLT_VERSION"}
+    assert any("gfx950" in v for v in validators)
+    assert len(entries) > 100 and all(len(e) == 4 and e[0].startswith("Gemm") and float(e[3]) > 0 for e in entries)
+    assert len({(e[0], e[1]) for e in entries}) == len(entries)          # one solution per (op, shape)

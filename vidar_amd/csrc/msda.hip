@@ -18,7 +18,10 @@
 // (they are contiguous in HBM) and re-read as broadcasts.  Workgroups are remapped so that each
 // XCD walks a contiguous band of queries: neighbouring BEV queries sample neighbouring pixels, so
 // a band keeps its slice of `value` resident in that XCD's private 4 MiB L2.
-// Backward: see the comment above msda_bwd_kernel (one atomic instruction per 128-byte corner line).
+// Backward: two grad_value strategies, chosen per call through the `workspace` argument -- the destination-binned
+// LDS accumulation below (default for real sizes) and the one-launch atomic scatter `msda_bwd_kernel` (small launches);
+// grad_loc / grad_w come from a gather shaped like the forward.  The fused entry points read the raw Linear outputs
+// (softmax / offset normalisation / reference add happen in the staging phase, see `Prep`).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
