@@ -2,7 +2,7 @@
 torch.cuda.set_sync_debug_mode("warn").  The reference synchronises per camera per layer (nonzero() at
 spatial_cross_attention.py:138, boolean indexing at vidar_head_base.py:441, :464-467, :636-644); DDP scaling
 needs the step to run ahead of the GPU, so the budget here is the ONE planned read of the visible-query list
-lengths (encoder.plan_frames) plus at most one more."""
+lengths (encoder.plan_frames); one more is tolerated."""
 import sys
 from pathlib import Path
 
