@@ -50,7 +50,7 @@ def test_plan_matches_torch_formulation(name, bev, bs):
         idx, valid, count = visible_query_index(mask)
         p_idx, p_valid, p_count = plan.index
         n = idx.shape[1]                                          # the plan pads to a multiple of 256 slots
-        assert p_idx.shape[1] >= n and p_idx.shape[1] - n < 256 and p_idx.shape[1] % 256 in (0, p_idx.shape[1] % 256)
+        assert p_idx.shape[1] == (min(bev * bev, (n + 255) // 256 * 256) if n else 0)
         assert torch.equal(p_valid[:, :n], valid) and not bool(p_valid[:, n:].any())
         assert torch.equal(p_idx[p_valid], idx[valid])            # visible queries, ascending, per camera
         assert torch.equal(p_count, count)
