@@ -92,27 +92,39 @@ class PhotoMetricDistortionMultiViewImage:
         self.saturation_lower, self.saturation_upper = saturation_range
         self.hue_delta = hue_delta
 
+    @staticmethod
+    def _coin_uniform(lo, hi):
+        """the reference's draw pattern: a fair coin first, the magnitude only when the coin says yes"""
+        return np.random.uniform(lo, hi) if np.random.randint(2) else None
+
+    def _distort(self, img):
+        img = np.array(img, dtype=np.float32)
+        shift = self._coin_uniform(-self.brightness_delta, self.brightness_delta)
+        if shift is not None:
+            img += shift
+        contrast_first = np.random.randint(2) == 1               # "mode": contrast before or after the HSV stage
+        gain = self._coin_uniform(self.contrast_lower, self.contrast_upper) if contrast_first else None
+        if gain is not None:
+            img *= gain
+        hsv = bgr2hsv(img)
+        sat = self._coin_uniform(self.saturation_lower, self.saturation_upper)
+        if sat is not None:
+            hsv[..., 1] *= sat
+        turn = self._coin_uniform(-self.hue_delta, self.hue_delta)
+        if turn is not None:
+            hue = hsv[..., 0] + turn
+            hue[hue > 360] -= 360
+            hue[hue < 0] += 360
+            hsv[..., 0] = hue
+        img = hsv2bgr(hsv)
+        gain = None if contrast_first else self._coin_uniform(self.contrast_lower, self.contrast_upper)
+        if gain is not None:
+            img *= gain
+        if np.random.randint(2):
+            img = img[..., np.random.permutation(3)]
+        return img
+
     def __call__(self, imgs):
-        rnd = np.random                                   # the reference uses numpy.random (`from numpy import random`)
-        out = []
-        for img in imgs:
-            img = np.array(img, dtype=np.float32)
-            if rnd.randint(2):
-                img += rnd.uniform(-self.brightness_delta, self.brightness_delta)
-            mode = rnd.randint(2)
-            if mode == 1 and rnd.randint(2):
-                img *= rnd.uniform(self.contrast_lower, self.contrast_upper)
-            img = bgr2hsv(img)
-            if rnd.randint(2):
-                img[..., 1] *= rnd.uniform(self.saturation_lower, self.saturation_upper)
-            if rnd.randint(2):
-                img[..., 0] += rnd.uniform(-self.hue_delta, self.hue_delta)
-                img[..., 0][img[..., 0] > 360] -= 360
-                img[..., 0][img[..., 0] < 0] += 360
-            img = hsv2bgr(img)
-            if mode == 0 and rnd.randint(2):
-                img *= rnd.uniform(self.contrast_lower, self.contrast_upper)
-            if rnd.randint(2):
-                img = img[..., rnd.permutation(3)]
-            out.append(img)
-        return out
+        """every image of the rig draws its own distortion, in order (numpy's global generator, like the reference's
+        `from numpy import random`)"""
+        return [self._distort(img) for img in imgs]
