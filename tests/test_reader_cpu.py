@@ -188,3 +188,33 @@ def test_training_reader_applies_one_augmentation_to_the_whole_queue(tmp_path):
     k = s["img_metas"][2]["cam2img"][0]
     np.testing.assert_allclose(k[0, 0], 50.0 * resize)     # focal length follows the resize
     np.testing.assert_allclose(s["img_metas"][2]["lidar2img"][0], k @ s["img_metas"][2]["lidar2cam"][0])
+
+
+def test_pcd_reader_matches_reference_class(tmp_path):
+    """binary .pcd parsing (OpenScene / nuPlan lidar) against the reference's own PointCloud + LoadNuPlanPointsFromFile,
+    and the key-frame handling of its multi-sweep loader with sweeps_num = 0 (tests/golden/make_pcd_golden.py)"""
+    from make_pcd_golden import write_pcd
+    from vidar_amd.data.reader import load_pcd_file
+    gold = np.load(GOLD / "pcd.npz")
+    pts = load_pcd_file(write_pcd(tmp_path / "a.pcd"))
+    assert pts.dtype == np.float32 and pts.shape == (257, 6)
+    np.testing.assert_array_equal(pts, gold["points"])
+    train = pts.copy(); train[:, 4] = 0; train[:, -1] = 0            # what ViDARSequenceDataset.frame does for nuplan
+    np.testing.assert_array_equal(train, gold["train_points"])
+    bad = tmp_path / "ascii.pcd"
+    bad.write_text("FIELDS x\nSIZE 4\nTYPE F\nCOUNT 1\nWIDTH 1\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 1\nDATA ascii\n1.0\n")
+    with pytest.raises(RuntimeError):
+        load_pcd_file(bad)
+
+
+def test_openscene_image_scale_follows_into_lidar2img():
+    from vidar_amd.data.reader import normalise_pad
+    img = np.random.default_rng(0).uniform(0, 255, (90, 120, 3)).astype(np.float32)
+    out, shape = normalise_pad([img], scale=2.0 / 3.0)
+    assert out.shape == (1, 3, 64, 96) and shape == (64, 96, 3)       # 60 x 80 resized, padded to /32
+    assert float(out[0, :, 60:].abs().max()) == 0 and float(out[0, :, :, 80:].abs().max()) == 0
+    flat = np.full((90, 120, 3), 100.0, np.float32)
+    out, _ = normalise_pad([flat], scale=2.0 / 3.0)
+    np.testing.assert_allclose(out[0, :, :60, :80].numpy(),
+                               np.broadcast_to((100.0 - np.array([103.530, 116.280, 123.675], np.float32))[:, None, None], (3, 60, 80)),
+                               rtol=0, atol=1e-4)

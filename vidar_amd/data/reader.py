@@ -44,6 +44,41 @@ def load_points_file(path, load_dim: int = 5) -> np.ndarray:
     return np.copy(pts).reshape(-1, load_dim)
 
 
+def load_pcd_file(path, fields=("x", "y", "z", "intensity", "ring", "lidar_info")) -> np.ndarray:
+    """binary `.pcd` cloud of the OpenScene / nuPlan logs -> float32 [N, 6] (x, y, z, intensity, ring, lidar_info):
+    LoadNuPlanPointsFromFile = PointCloud.parse_from_file(...).to_pcd_bin2().T
+    (datasets/pipelines/nuplan_loading.py:73-181, :193-203).  Header keys as in the PCD format; only DATA binary
+    with COUNT 1 per field is accepted, like the reference."""
+    kinds = {"I": "int", "U": "uint", "F": "float"}
+    with open(path, "rb") as f:
+        hdr = {}
+        while True:
+            line = f.readline().decode("utf8").strip()
+            if not line:
+                raise RuntimeError(f"{path}: truncated .pcd header")
+            if line.startswith("#"):
+                continue
+            cols = line.split()
+            hdr[cols[0].lower()] = cols[1:] if len(cols) > 2 else cols[1]
+            if cols[0].lower() == "data":
+                break
+        as_list = lambda v: v if isinstance(v, list) else [v]
+        names, sizes, types, counts = (as_list(hdr[k]) for k in ("fields", "size", "type", "count"))
+        if any(int(c) != 1 for c in counts):
+            raise RuntimeError('"count" has to be 1')
+        if not len(names) == len(sizes) == len(types) == len(counts):
+            raise RuntimeError("fields/size/type/count field number are inconsistent")
+        if hdr["data"] != "binary":
+            raise RuntimeError(f'Un-supported data foramt: {hdr["data"]}. "binary" is expected.')
+        row = np.dtype([(n, getattr(np, kinds[t] + str(int(sz) * 8))) for n, sz, t in zip(names, sizes, types)])
+        need = row.itemsize * int(hdr["points"])
+        buf = f.read(need)                                   # trailing garbage after the points is ignored
+        if len(buf) != need:
+            raise RuntimeError(f"Incomplete pointcloud stream: {need} bytes expected, {len(buf)} got")
+    pts = np.frombuffer(buf, row)
+    return np.stack([np.asarray(pts[k], dtype=np.float32) for k in fields], 1)
+
+
 def remove_close(points: np.ndarray, radius: float = 1.0, ego_mask=None) -> np.ndarray:
     """drop |x|<r & |y|<r (loading.py:76-97), then the ego-vehicle box (:190-215; inclusive bounds)"""
     close = (np.abs(points[:, 0]) < radius) & (np.abs(points[:, 1]) < radius)
@@ -126,14 +161,22 @@ def load_raw_images(paths: Sequence) -> list:
 
 
 def normalise_pad(imgs: Sequence, mean=IMG_NORM["mean"], std=IMG_NORM["std"], to_rgb=IMG_NORM["to_rgb"],
-                  size_divisor: int = 32):
-    """NormalizeMultiviewImage + PadMultiViewImage(size_divisor) -> (float32 [cams, 3, H_pad, W_pad], padded shape);
-    `to_rgb` flips the channels before normalising like mmcv.imnormalize; zero padding at bottom / right."""
+                  size_divisor: int = 32, scale=None):
+    """NormalizeMultiviewImage [+ RandomScaleImageMultiViewImage(scales=[scale])] + PadMultiViewImage(size_divisor)
+    -> (float32 [cams, 3, H_pad, W_pad], padded shape); `to_rgb` flips the channels before normalising like
+    mmcv.imnormalize; zero padding at bottom / right.  `scale` (OpenScene: 2/3, transform_3d.py:295-327) resizes to
+    (int(h*scale), int(w*scale)) with bilinear interpolation at pixel centres ([3P] mmcv.imresize = cv2.INTER_LINEAR;
+    torch's bilinear, align_corners=False, no antialias, is the same sampling rule) -- the caller scales lidar2img."""
     out = []
     for a in imgs:
         if to_rgb:
             a = a[..., ::-1]
         a = (a - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+        if scale is not None:
+            hs, ws = int(a.shape[0] * scale), int(a.shape[1] * scale)
+            t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))[None]
+            a = torch.nn.functional.interpolate(t, size=(hs, ws), mode="bilinear", align_corners=False)[0] \
+                .permute(1, 2, 0).numpy()
         h, w = a.shape[:2]
         H = (h + size_divisor - 1) // size_divisor * size_divisor
         W = (w + size_divisor - 1) // size_divisor * size_divisor
@@ -154,15 +197,15 @@ class TrainAugment:
     """PhotoMetricDistortionMultiViewImage then CropResizeFlipImage (config :308-311), `aug_param` carried from
     frame to frame of a queue so that every frame of a sample gets the same crop / resize / flip."""
 
-    def __init__(self, data_aug_conf=None, photometric=True):
+    def __init__(self, data_aug_conf=None, photometric=True, crop_resize_flip=True):
         from .augment import CropResizeFlipImage, PhotoMetricDistortionMultiViewImage
         self.photo = PhotoMetricDistortionMultiViewImage() if photometric else None
-        self.crop = CropResizeFlipImage(data_aug_conf, training=True)
+        self.crop = CropResizeFlipImage(data_aug_conf, training=True) if crop_resize_flip else None
 
     def __call__(self, imgs, meta, aug_param):
         if self.photo is not None:
             imgs = self.photo(imgs)
-        return self.crop(imgs, meta, aug_param)
+        return self.crop(imgs, meta, aug_param) if self.crop is not None else imgs
 
 
 class ViDARSequenceDataset:
@@ -173,15 +216,18 @@ class ViDARSequenceDataset:
     def __init__(self, ann_file, data_root="", queue_length=4, future_length=1, test_mode=False,
                  load_interval=1, load_frame_interval=None, rand_frame_interval=(1,),
                  ego_mask=(-0.8, -1.5, 0.8, 2.5), sweeps_num=2, voxel_size=(1.0, 1.0, 1.0),
-                 point_cloud_range=PC_RANGE, max_voxels=50000, dataset="nuscenes", augment=None):
+                 point_cloud_range=PC_RANGE, max_voxels=50000, dataset="nuscenes", augment=None, img_scale=None):
         self.infos, self.metadata = load_infos(ann_file, load_interval)
         self.data_root, self.dataset = str(data_root), dataset
         self.queue_length, self.future_length, self.test_mode = queue_length, future_length, test_mode
         self.rand_frame_interval, self.ego_mask = tuple(rand_frame_interval), ego_mask
         self.sweeps_num, self.voxel_size = sweeps_num, voxel_size
         self.point_cloud_range, self.max_voxels = point_cloud_range, max_voxels
-        # True: the released training augmentation; a callable (imgs, meta, aug_param) -> imgs; None: none
-        self.augment = TrainAugment() if augment is True else augment
+        # True: the released training augmentation (nuScenes: photometric + crop/resize/flip, config :308-311;
+        # OpenScene: photometric only, OpenScene config :297-299); a callable (imgs, meta, aug_param) -> imgs; None: none
+        self.augment = TrainAugment(crop_resize_flip=dataset == "nuscenes") if augment is True else augment
+        # OpenScene resizes the normalised images by 2/3 (RandomScaleImageMultiViewImage) in train AND test pipelines
+        self.img_scale = (2.0 / 3.0 if dataset == "nuplan" else None) if img_scale is None else img_scale
         self.usable_index = usable_indices(self.infos, future_length, queue_length, test_mode, load_frame_interval)
 
     def __len__(self):
@@ -193,10 +239,16 @@ class ViDARSequenceDataset:
     def frame(self, index, with_images=True, aug_param=None):
         """one frame through the pipeline -> record dict(img, points, img_metas[, aug_param])"""
         meta = frame_meta_from_info(copy.deepcopy(self.infos[index]), self.dataset, self.data_root)
-        pts = load_points_file(self._path(meta["pts_filename"]))
-        if not self.test_mode:                                       # train pipeline: sweeps + voxel subsample
+        path = self._path(meta["pts_filename"])
+        pts = load_pcd_file(path) if path.endswith(".pcd") else load_points_file(path)
+        if not self.test_mode and self.dataset == "nuscenes":        # train pipeline: sweeps + voxel subsample
             sweeps = [dict(s, data_path=self._path(s["data_path"])) for s in meta.get("sweeps", [])]
             pts = load_multi_sweeps(pts, sweeps, meta["timestamp"], self.sweeps_num, ego_mask=self.ego_mask)
+            pts = voxel_subsample(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
+        elif not self.test_mode:                                     # OpenScene: sweeps_num = 0, six columns
+            pts = np.array(pts, dtype=np.float32, copy=True)         # LoadNuPlanPointsFromMultiSweeps with no sweeps:
+            pts[:, 4] = 0                                            # key-frame time slot, then hard_sweeps_timestamp
+            pts[:, -1] = 0                                           # on the LAST column (nuplan_loading.py:283-288)
             pts = voxel_subsample(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
         rec = dict(points=torch.from_numpy(np.ascontiguousarray(pts)), img_metas=meta)
         if with_images:
@@ -205,7 +257,10 @@ class ViDARSequenceDataset:
                 aug_param = {} if aug_param is None else aug_param
                 imgs = self.augment(imgs, meta, aug_param)
                 rec["aug_param"] = aug_param
-            img, shape = normalise_pad(imgs)
+            img, shape = normalise_pad(imgs, scale=self.img_scale)
+            if self.img_scale is not None:                           # transform_3d.py:317-323
+                k = np.eye(4); k[0, 0] = k[1, 1] = self.img_scale
+                meta["lidar2img"] = [k @ np.asarray(a) for a in meta["lidar2img"]]
             n = img.shape[0]
             meta.update(img_shape=[shape] * n, pad_shape=[shape] * n, img_norm_cfg=dict(IMG_NORM))
             rec["img"] = img
