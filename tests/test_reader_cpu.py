@@ -218,3 +218,14 @@ def test_openscene_image_scale_follows_into_lidar2img():
     np.testing.assert_allclose(out[0, :, :60, :80].numpy(),
                                np.broadcast_to((100.0 - np.array([103.530, 116.280, 123.675], np.float32))[:, None, None], (3, 60, 80)),
                                rtol=0, atol=1e-4)
+
+
+def test_getitem_retries_when_the_future_leaves_the_scene(tmp_path):
+    """rand_frame_interval = 2 makes the future of index 3 (frames 3, 5) fine but of index 4 (4, 6 -> scene-b) not:
+    the reader retries with interval 1 like the template (:199-219) instead of returning None"""
+    from vidar_amd.data.reader import ViDARSequenceDataset
+    ds = ViDARSequenceDataset(_mini_nuscenes(tmp_path), queue_length=1, future_length=1, rand_frame_interval=(2,))
+    np.random.seed(0)
+    assert ds._prepare(4) is None and ds._prepare(4, rand_interval=1) is not None
+    s = ds[ds.usable_index.index(4)]
+    assert s is not None and s["img_metas"][1]["sample_idx"] == "tok4"

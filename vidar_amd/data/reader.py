@@ -266,9 +266,8 @@ class ViDARSequenceDataset:
             rec["img"] = img
         return rec
 
-    def __getitem__(self, i):
-        index = self.usable_index[i]
-        interval = int(np.random.choice(self.rand_frame_interval, 1)[0])
+    def _prepare(self, index, rand_interval=None):
+        interval = int(np.random.choice(self.rand_frame_interval, 1)[0]) if rand_interval is None else rand_interval
         prev, fut = frame_index_lists(index, self.queue_length, self.future_length, interval, len(self.infos))
         previous_queue, aug_param = [], None
         for k in prev:                       # the first frame draws the augmentation, the others replay it (:116-124)
@@ -277,3 +276,19 @@ class ViDARSequenceDataset:
             previous_queue.append(rec)
         future_queue = [self.frame(k, with_images=False) for k in fut]
         return union2one(previous_queue, future_queue, self.future_length, self.ego_mask)
+
+    def __getitem__(self, i):
+        """the template's retry protocol (:199-219): a sample whose future leaves its scene is retried once with
+        frame interval 1, then replaced by a random other sample (training) / the next one (testing)"""
+        rand_interval = None
+        while True:
+            data = self._prepare(self.usable_index[i], rand_interval)
+            if data is not None:
+                return data
+            if self.test_mode:
+                i += 1
+            elif rand_interval is None:
+                rand_interval = 1
+            else:
+                i = int(np.random.choice(len(self.usable_index)))       # [3P] mmdet3d _rand_another (single group)
+                rand_interval = None
