@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/test.py \
         vidar_1_8_nusc_3future --samples 64 --submission submission/model
 
-Every rank evaluates samples rank, rank+W, ... (synthetic generator: no dataset code in scope), the
+Every rank evaluates samples rank, rank+W, ... (synthetic generator, or with --ann-file the validation info pkl
+read by vidar_amd.data in test mode: full history required, key-frame cloud only, no augmentation), the
 per-sample `frame.k` dicts are gathered over the process group (RCCL) and rank 0 prints the
 reference's summary (chamfer distance, L1 and AbsRel ray errors per future frame)."""
 import argparse
@@ -33,6 +34,8 @@ def main(argv=None):
     ap.add_argument("--submission", help="directory for the per-sample depth files (vidar.py:503-519)")
     ap.add_argument("--out", help="write the summary as JSON")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ann-file", help="validation info pkl (data/nuscenes/nuscenes_infos_temporal_val.pkl)")
+    ap.add_argument("--data-root", default="")
     args = ap.parse_args(argv)
 
     from vidar_amd import checkpoint as C
@@ -71,7 +74,18 @@ def main(argv=None):
             b["img"] = torch.randn(1, T_img, meta["num_cams"], 3, *meta["img_hw"], generator=g).to(dev)
         return b
 
-    results = E.multi_gpu_test(model, batch, args.samples)
+    n_samples = args.samples
+    if args.ann_file:
+        from vidar_amd.data import ViDARSequenceDataset
+        ds = ViDARSequenceDataset(args.ann_file, data_root=args.data_root, queue_length=meta["queue_length"],
+                                  future_length=n_future, test_mode=True,
+                                  dataset="nuplan" if "OpenScene" in meta["name"] else "nuscenes")
+        n_samples = len(ds) if args.samples <= 0 else min(args.samples, len(ds))
+
+        def batch(i):                                                  # noqa: F811  (real data replaces the generator)
+            s_ = ds[i]
+            return dict(img=s_["img"][None].to(dev), img_metas=[s_["img_metas"]], gt_points=[s_["gt_points"].to(dev)])
+    results = E.multi_gpu_test(model, batch, n_samples)
     if rank == 0:
         summary = E.summarize(results)
         print(E.format_summary(summary), flush=True)
