@@ -1,0 +1,176 @@
+"""GPU parity at BASELINE ray / point counts: the HIP dvr family and KNN against the CPU oracles
+(not against themselves).
+
+Reference kernels restated by the oracle: third_lib/dvxlr/dvxlr.cu:185-456, dvxlr_v2.cu:147-426,
+dvr/dvr.cu:87-316 and :409-626, chamferdist/knn_cpu.cpp:7-58.  Ray sets:
+one frame of 30 000 rays, five frames (150 000), and the OpenScene stress shape of config c4
+(T = 4 + 6 frames, 9 x 30 000 rays, origins off-centre by up to 30 voxels).  Voxel index lists,
+gt_dist, indicator and ray_pred: bit-exact; pred / dd: 2e-5 (fp64 summation order).  Every case is
+checked under the three launch variants (plain, ranked workgroups, ranked + prefill padding)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chamfer as C
+from oracle import dvr as O
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {"plain": (1 << 30, 0), "ranked": (0, 0), "ranked-prefill": (0, 1)}
+VOXEL_M = 0.512
+SHAPES = {
+    "1x30k": dict(T=1, rays_per_frame=30000, pad=0, origin_jitter=0.0),
+    "5x30k": dict(T=5, rays_per_frame=30000, pad=77, origin_jitter=4.0),
+    # c4: 9 x 30 000 rays over T = 10 frames, origins up to 30 voxels off centre
+    "c4_10x27k": dict(T=10, rays_per_frame=27000, pad=0, origin_jitter=30 * VOXEL_M),
+}
+
+
+def _set_variant(name):
+    from vidar_amd._lib import lib
+    thr, pad = VARIANTS[name]
+    return lib().vidar_dvr_set_sort_min_waves(thr), lib().vidar_dvxlr_set_pad_mode(pad)
+
+
+def _restore(prev):
+    from vidar_amd._lib import lib
+    lib().vidar_dvr_set_sort_min_waves(prev[0]); lib().vidar_dvxlr_set_pad_mode(prev[1])
+
+
+def _dev(*arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def _same(gpu, host):
+    """bitwise equality of a device tensor and a host array, compared on the device in slabs."""
+    h = torch.from_numpy(host)
+    assert gpu.shape == h.shape
+    g = gpu.reshape(-1); h = h.reshape(-1)
+    step = 1 << 28
+    for s in range(0, g.numel(), step):
+        if not torch.equal(g[s:s + step], h[s:s + step].cuda()):
+            return False
+    return True
+
+
+def _close(gpu, host, rtol=2e-5, atol_rel=2e-6):
+    scale = max(1.0, float(np.abs(host).max())) if host.size else 1.0
+    h = torch.from_numpy(host)
+    g = gpu.reshape(-1); h = h.reshape(-1)
+    step = 1 << 28
+    for s in range(0, g.numel(), step):
+        torch.testing.assert_close(g[s:s + step], h[s:s + step].cuda(), rtol=rtol, atol=atol_rel * scale)
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_dvxlr_and_v2_match_oracle_at_baseline_size(shape):
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvxlr, dvxlr_v2
+    sigma, origin, points, tindex = ray_set(seed=21, N=1, **SHAPES[shape])
+    regul = np.random.default_rng(7).standard_normal(sigma.shape).astype(np.float32)
+    o = O.dvxlr_render(sigma, origin, points, tindex, regul)
+    cnt = (o[5] >= 0).sum(-1)
+    assert int((o[0] >= 0).sum()) > 0.9 * SHAPES[shape]["T"] * SHAPES[shape]["rays_per_frame"]
+    assert 100 < int(cnt.max()) <= 1026              # the long rays are in the set
+    d = _dev(sigma, origin, points, tindex, regul)
+    prev = _set_variant("plain")
+    try:
+        for variant in VARIANTS:
+            _set_variant(variant)
+            pred, gt, dd, idx = dvxlr.render(*d[:4])
+            assert _same(idx, o[3]), f"{variant}: dvxlr voxel index lists differ from the oracle"
+            assert _same(gt, o[1]), f"{variant}: gt_dist"
+            _close(pred, o[0]); _close(dd, o[2])
+            del pred, gt, dd, idx
+            pred, gt, dd, idx, rp, ind = dvxlr_v2.render_v2(*d)
+            assert _same(idx, o[3]), f"{variant}: dvxlr_v2 voxel index lists differ from the oracle"
+            assert _same(ind, o[5]), f"{variant}: indicator"
+            assert _same(rp, o[4]), f"{variant}: ray_pred"
+            assert _same(gt, o[1]), f"{variant}: gt_dist"
+            _close(pred, o[0]); _close(dd, o[2])
+            del pred, gt, dd, idx, rp, ind
+    finally:
+        _restore(prev)
+
+
+@pytest.mark.parametrize("shape", ["1x30k", "5x30k"])
+def test_get_grad_sigma_matches_oracle_at_baseline_size(shape):
+    """dvxlr.cu:63-156 / dvxlr_v2.cu:12-115: scatter of dd-weighted row gradients into the volume."""
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvxlr, dvxlr_v2
+    sigma, origin, points, tindex = ray_set(seed=22, N=1, **SHAPES[shape])
+    regul = np.random.default_rng(7).standard_normal(sigma.shape).astype(np.float32)
+    o = O.dvxlr_render(sigma, origin, points, tindex, regul)
+    rng = np.random.default_rng(8)
+    em = rng.standard_normal(o[0].shape).astype(np.float32)[..., None] * o[2]
+    grp = rng.standard_normal(o[4].shape).astype(np.float32)
+    og = O.dvxlr_get_grad_sigma(em, o[3], tindex, sigma.shape)
+    og2 = O.dvxlr_get_grad_sigma(em, o[3], tindex, sigma.shape, o[5], grp)
+    dem, didx, dt, dsig, dind, dgrp = _dev(em, o[3], tindex, sigma, o[5], grp)
+    g = dvxlr.get_grad_sigma(dem, didx, dt, dsig)[0]
+    _close(g, og, rtol=1e-4, atol_rel=1e-5)
+    g1, g2 = dvxlr_v2.get_grad_sigma_v2(dem, didx, dt, dsig, dind, dgrp)
+    _close(g1, og2[0], rtol=1e-4, atol_rel=1e-5); _close(g2, og2[1], rtol=1e-4, atol_rel=1e-5)
+
+
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_dvr_matches_oracle_at_baseline_size(shape):
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvr
+    sigma, origin, points, tindex = ray_set(seed=23, N=1, **SHAPES[shape])
+    grid = list(sigma.shape[1:])
+    of = {ph: O.render_forward(sigma, origin, points, tindex, ph) for ph in ("train", "test")}
+    orr = {ls: O.render(sigma, origin, points, tindex, ls) for ls in ("l2", "l1")}
+    d = _dev(sigma, origin, points, tindex)
+    prev = _set_variant("plain")
+    try:
+        for variant in ("plain", "ranked"):
+            _set_variant(variant)
+            for ph in ("train", "test"):
+                pred, gt = dvr.render_forward(*d, grid, ph)
+                assert _same(gt, of[ph][1]), f"{variant}/{ph}: gt_dist"
+                _close(pred, of[ph][0])
+            for ls in ("l2", "l1"):
+                pred, gt, grad = dvr.render(*d, ls)
+                assert _same(gt, orr[ls][1]), f"{variant}/{ls}: gt_dist"
+                _close(pred, orr[ls][0])
+                want = orr[ls][2]
+                if ls == "l2":
+                    _close(grad, want, rtol=1e-3, atol_rel=1e-4)
+                else:
+                    # sign(pred - gt) of a ray whose |pred - gt| is at rounding level may flip: compare in
+                    # aggregate and demand elementwise agreement on all but a handful of voxels
+                    bad = (grad.cpu().numpy() - want)
+                    tol = 1e-3 * np.abs(want) + 1e-4 * max(1.0, float(np.abs(want).max()))
+                    assert (np.abs(bad) > tol).mean() < 1e-5
+    finally:
+        _restore(prev)
+
+
+def test_init_matches_oracle_at_baseline_size():
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvr, dvxlr
+    sigma, origin, points, tindex = ray_set(seed=24, N=1, **SHAPES["5x30k"])
+    grid = list(sigma.shape[1:])
+    ref = O.init(points, tindex, grid)
+    for m in (dvr, dvxlr):
+        assert _same(m.init(*_dev(points, tindex), grid), ref)
+
+
+@pytest.mark.parametrize("P1,P2,dup", [(30000, 30000, False), (30011, 34567, True)])
+def test_knn_bit_exact_at_eval_size(P1, P2, dup):
+    """knn_cpu.cpp:7-58 at the evaluation size: nearest index (lowest index wins ties) and squared
+    distance bit-exact, both directions, including duplicated target points (exact ties)."""
+    from test_oracle_chamfer import clouds
+    from vidar_amd.third_lib.chamferdist import _C
+    a, b = clouds(31, 1, P1, P2, dup=dup)
+    if dup:                       # many exact ties spread over the chunk boundaries of the kernel
+        b[0, 5000:5000 + 2000] = b[0, 25000:25000 + 2000]
+        a[0, 100:2100] = b[0, 25000:25000 + 2000]
+    t = lambda x: torch.from_numpy(x).cuda()
+    l1 = torch.tensor([P1]).cuda(); l2 = torch.tensor([P2]).cuda()
+    for x, y, lx, ly in ((a, b, l1, l2), (b, a, l2, l1)):
+        oi, od = C.knn_points_idx(x, y)
+        gi, gd = _C.knn_points_idx(t(x), t(y), lx, ly, 1, -1)
+        assert np.array_equal(gi.cpu().numpy(), oi), "nearest-neighbour indices differ from the oracle"
+        assert np.array_equal(gd.cpu().numpy(), od), "squared distances differ from the oracle"

@@ -37,6 +37,20 @@ def test_knn_matches_reference_build(shape, ref_modules):
     np.testing.assert_allclose(r2.numpy(), o2, rtol=1e-5, atol=1e-5)
 
 
+def test_knn_matches_reference_build_at_eval_size(ref_modules):
+    """30 000 x 30 000 points (the evaluation size; knn_cpu.cpp:7-58 is a single-threaded O(P1*P2)
+    scan): the numpy restatement the GPU tests compare with is bit-exact with the reference's build."""
+    ref = ref_modules("ref_chamferdist_C")
+    a, b = clouds(31, 1, 30000, 30000, dup=True)
+    b[0, 5000:7000] = b[0, 25000:27000]            # exact ties far apart: lowest index must win
+    a[0, 100:2100] = b[0, 25000:27000]
+    l = torch.tensor([30000])
+    ri, rd = ref.knn_points_idx(torch.from_numpy(a), torch.from_numpy(b), l, l, 1, -1)
+    oi, od = C.knn_points_idx(a, b)
+    assert np.array_equal(ri.numpy(), oi) and np.array_equal(rd.numpy(), od)
+    assert int((oi[0, 100:2100, 0] < 7000).all())
+
+
 def test_knn_empty_target(ref_modules):
     ref = ref_modules("ref_chamferdist_C")
     a, b = clouds(2, 1, 10, 5)

@@ -111,3 +111,24 @@ def test_oracle_matches_golden(name):
     r = O.render(sigma, origin, points, tindex, "l2")
     assert np.array_equal(r[0], g["dvr_pred"]) and np.array_equal(r[1], g["dvr_gt"])
     assert np.allclose(r[2].sum(axis=(2, 3)), g["dvr_grad_zsum"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("kw", [dict(T=1, rays_per_frame=30000),
+                                dict(T=10, rays_per_frame=27000, origin_jitter=30 * 0.512)],
+                         ids=["1x30k", "c4_10x27k"])
+def test_oracle_matches_reference_build_at_baseline_size(kw, ref_modules):
+    """the ray sets of tests/test_fullsize_parity_gpu.py (one 30 000-ray frame; the OpenScene stress
+    shape: 10 frames, 270 000 rays, origins up to 30 voxels off centre): the C restatement the GPU is
+    compared with is bit-exact with the reference's own dvxlr kernel (host build) at that size too."""
+    from vidar_amd.synthetic import ray_set
+    ref = ref_modules("ref_dvxlr")
+    sigma, origin, points, tindex = ray_set(seed=21, N=1, **kw)
+    r = ref.render(ts(sigma), ts(origin), ts(points), ts(tindex))
+    o = O.dvxlr_render(sigma, origin, points, tindex)
+    for a, b, nm in zip(r, o, ["pred_dist", "gt_dist", "dd_dsigma", "indices"]):
+        assert torch.equal(a, ts(b)), f"{nm} differs (bit-exact expected)"
+    ref2 = ref_modules("ref_dvr")
+    rf = ref2.render_forward(ts(sigma), ts(origin), ts(points), ts(tindex), list(sigma.shape[1:]), "train")
+    of = O.render_forward(sigma, origin, points, tindex, "train")
+    for a, b in zip(rf, of):
+        assert torch.equal(a, ts(b))

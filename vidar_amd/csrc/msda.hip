@@ -375,18 +375,25 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
 // flushes the non-zero window lines with one atomic per line: ~2-3 M requests instead of 61 M.
 // grad_loc / grad_w come from a gather kernel shaped like the forward (no atomics at all).
 // ---------------------------------------------------------------------------------------------
-constexpr int kTile = 8;                       // tile edge (top-left corner pixels)
+#ifndef VIDAR_MSDA_TILE_SHIFT
+#define VIDAR_MSDA_TILE_SHIFT 3
+#endif
+constexpr int kTileShift = VIDAR_MSDA_TILE_SHIFT;
+constexpr int kTile = 1 << kTileShift;         // tile edge (top-left corner pixels)
 constexpr int kWin = kTile + 1;                // window edge (corner pixels)
 constexpr int kWinLines = kWin * kWin;         // 81 lines of 32 floats
+#ifndef VIDAR_MSDA_SHARED_WIN
+#define VIDAR_MSDA_SHARED_WIN 1
+#endif
+// 1: the 4 waves of a workgroup accumulate ONE window with ds_add_f32 (no read-modify-write chain, one flush per
+//    4096 samples); 0: a private window per wave, plain read-modify-writes (round 2)
+constexpr bool kSharedWin = VIDAR_MSDA_SHARED_WIN != 0;
 #ifndef VIDAR_MSDA_CHUNK
-#define VIDAR_MSDA_CHUNK 1024
+#define VIDAR_MSDA_CHUNK (VIDAR_MSDA_SHARED_WIN ? 4096 : 1024)
 #endif
-#ifndef VIDAR_MSDA_TWAVES
-#define VIDAR_MSDA_TWAVES 2
-#endif
-constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per wave (tuning sweep: tools/tune_msda_tile.sh)
+constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor (tuning sweep: tools/tune_msda_tile.sh)
 constexpr int kMaxL = 16;                      // levels supported by the binned path
-constexpr int kTWaves = VIDAR_MSDA_TWAVES;     // waves (= chunks) per workgroup of the tile kernel
+constexpr int kTWaves = 4;                     // waves per workgroup of the tile kernel
 
 struct LevelTab {
   int Hl[kMaxL], Wl[kMaxL], ntx[kMaxL], toff[kMaxL];
@@ -398,8 +405,8 @@ __device__ __forceinline__ void build_tab(LevelTab& t, const int64_t* __restrict
     int off = 0;
     for (int l = 0; l < L; ++l) {
       const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-      t.Hl[l] = Hl; t.Wl[l] = Wl; t.ntx[l] = (Wl >> 3) + 1; t.toff[l] = off;
-      off += t.ntx[l] * ((Hl >> 3) + 1);       // px = floor(x)+1 in [0, Wl], py likewise
+      t.Hl[l] = Hl; t.Wl[l] = Wl; t.ntx[l] = (Wl >> kTileShift) + 1; t.toff[l] = off;
+      off += t.ntx[l] * ((Hl >> kTileShift) + 1);       // px = floor(x)+1 in [0, Wl], py likewise
     }
     t.T = off;
   }
@@ -414,7 +421,7 @@ __device__ __forceinline__ int sample_tile(const LevelTab& t, const float* __res
   const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
   if (!(y > -1.f && x > -1.f && y < Hl && x < Wl)) return -1;
   const int px = (int)floorf(x) + 1, py = (int)floorf(y) + 1;
-  return (py >> 3) * t.ntx[l] + (px >> 3);
+  return (py >> kTileShift) * t.ntx[l] + (px >> kTileShift);
 }
 
 // Counting sort, passes 1 and 3.  Global int atomics on the tile counters would put the sort on the
@@ -424,7 +431,7 @@ __device__ __forceinline__ int sample_tile(const LevelTab& t, const float* __res
 // counters once per (workgroup, touched tile).
 constexpr int kBinQ = 512;                     // queries per workgroup
 constexpr int kBinSamples = 16;                // samples per thread held in registers (fill pass)
-constexpr int kMaxTilesLds = 8000;             // LDS histogram capacity: 2 x 4 B x 8000 + the level table < 64 KB
+constexpr int kMaxTilesLds = 16000;            // LDS histogram capacity: 2 x 4 B x 16000 + the level table < 160 KB
 
 template <bool FILL>
 __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
@@ -435,7 +442,7 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
   build_tab(t, shapes, L);
   const int plane = blockIdx.y;                // (b * H + h) * L + l
   const int l = plane % L, h = (plane / L) % H, b = plane / L / H;
-  const int ntl = t.ntx[l] * ((t.Hl[l] >> 3) + 1);
+  const int ntl = t.ntx[l] * ((t.Hl[l] >> kTileShift) + 1);
   const int q0 = blockIdx.x * kBinQ, nq = min(kBinQ, Nq - q0);
   const int n = nq * P;                        // samples of this workgroup
   const int LP = L * P;
@@ -487,7 +494,8 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
 }
 
 // one workgroup: counts -> exclusive prefix (left in `counts`, it becomes the fill cursor) and the
-// chunk table {bin, first record, number of records}
+// chunk table: two int4 per chunk, {first record, number of records, level, batch element} and
+// {head, tile row, tile column, 0}, so the accumulate kernel needs no level table of its own
 constexpr int kScanThreads = 1024;
 __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
     const int64_t* __restrict__ shapes, int* __restrict__ counts, int4* __restrict__ desc,
@@ -510,38 +518,61 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
     __syncthreads();
   }
   int s = s_sum[threadIdx.x] - cs, k = s_chk[threadIdx.x] - cc;
-  for (int b = r0; b < r1; ++b) {
-    const int c = counts[b];
-    counts[b] = s;
-    for (int i = 0; i < c; i += kChunk) desc[k++] = make_int4(b, s + i, min(kChunk, c - i), 0);
+  for (int bin = r0; bin < r1; ++bin) {
+    const int c = counts[bin];
+    counts[bin] = s;
+    if (c) {
+      const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
+      int l = 0;
+      while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
+      const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
+      for (int i = 0; i < c; i += kChunk) {
+        desc[2 * k] = make_int4(s + i, min(kChunk, c - i), l, b);
+        desc[2 * k + 1] = make_int4(h, ty, tx, 0);
+        ++k;
+      }
+    }
     s += c;
   }
   if (threadIdx.x == kScanThreads - 1) *n_chunks = s_chk[threadIdx.x];
 }
 
+// Accumulate kernel.  One chunk (<= kChunk records of one destination tile) per workgroup of 4 waves.
+// All 64 lanes of a wave work on ONE sample: lanes 0-31 own the 32 channels of the left corner column,
+// lanes 32-63 the right column; the top row and the bottom row are two LDS operations.  Round 2 spent
+// ~18 VALU instructions per sample on handing the per-sample scalars to the lanes (readlane + select
+// chains) and was VALU-issue bound at 0.5 ms for the 15 M samples of SpatialCrossAttention.  Now lane k
+// of a 64-sample batch prepares sample k and parks its four corner weights in LDS as two 8-byte records
+// (left column, right column); in the sample loop every lane picks its column's (top, bottom) pair with ONE
+// ds_read_b64 whose address does not depend on the sample (immediate offsets), the window offset and the
+// grad_out line travel by v_readlane (2 per sample), and the window is shared by the workgroup's waves
+// and accumulated with ds_add_f32 (no return value -> no read-modify-write dependency chain).
 __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
     const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
     int H, int L, int P) {
-  __shared__ LevelTab t;
-  __shared__ float s_win[kTWaves][kWinLines * kCh];
-  build_tab(t, shapes, L);
+  __shared__ float s_win[kSharedWin ? 1 : kTWaves][kWinLines * kCh];
+  __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, bottom-left, top-right, bottom-right}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int chunk = blockIdx.x * kTWaves + wave;
-  if (chunk >= *n_chunks) return;                      // wave-uniform
-  const int4 d = desc[chunk];
-  const int bin = d.x, s0 = d.y, n = d.z;
-  const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
-  int l = 0;
-  while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
-  const int Hl = t.Hl[l], Wl = t.Wl[l];
-  const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
-  float* win = s_win[wave];
-  for (int i = lane; i < kWinLines * kCh; i += 64) win[i] = 0.f;
+  const int chunk = kSharedWin ? blockIdx.x : blockIdx.x * kTWaves + wave;
+  if (chunk >= *n_chunks) return;                      // workgroup-uniform (shared window) / wave-uniform
+  const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
+  const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
+  const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+  float* win = s_win[kSharedWin ? 0 : wave];
+  if (kSharedWin) {
+    for (int i = threadIdx.x; i < kWinLines * kCh; i += 64 * kTWaves) win[i] = 0.f;
+    __syncthreads();
+  } else {
+    for (int i = lane; i < kWinLines * kCh; i += 64) win[i] = 0.f;
+  }
   const int LP = L * P;
-  const int rmask = lane >= 32 ? -1 : 0;
-  for (int base = 0; base < n; base += 64) {
+  const float2* par = reinterpret_cast<const float2*>(&s_par[wave][0]) + (lane >> 5);
+  float* wl = win + lane;
+  const float* gl = grad_out + (lane & 31);
+  const int step = kSharedWin ? 64 * kTWaves : 64;
+  for (int base = kSharedWin ? wave * 64 : 0; base < n; base += step) {
     // lane k prepares sample base+k: window offset of its top-left corner, the four corner weights
     // (times the attention weight) and the offset of its grad_out line
     const bool valid = base + lane < n;
@@ -551,40 +582,53 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
     const int h0 = (int)floorf(y), w0 = (int)floorf(x);
     const float lh = y - h0, lw = x - w0;
-    const float w_top_l = (1.f - lh) * (1.f - lw) * aw, w_top_r = (1.f - lh) * lw * aw;
-    const float w_bot_l = lh * (1.f - lw) * aw, w_bot_r = lh * lw * aw;
+    const float hh = (1.f - lh) * aw, lha = lh * aw;
+    __builtin_amdgcn_wave_barrier();                   // the previous batch's reads of s_par are done (in-order LDS)
+    s_par[wave][lane] = make_float4(hh * (1.f - lw), lha * (1.f - lw), hh * lw, lha * lw);
     const int off = (min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1)) * kCh;
     const int gofs = (s / LP) * kCh;
-    const int m = min(64, n - base);
+    __builtin_amdgcn_wave_barrier();
+    // groups of 8 samples, software-pipelined by hand: the weight pairs and grad_out lines of group k+1
+    // are requested before the LDS adds of group k (the compiler keeps LDS reads behind LDS atomics)
+    float g[8], gn[8];
+    float2 a[8], an[8];
 #pragma unroll
-    for (int j0 = 0; j0 < 64; j0 += 8) {
-      if (j0 >= m) break;                              // wave-uniform
-      float g[8];
+    for (int u = 0; u < 8; ++u) {
+      g[u] = gl[__builtin_amdgcn_readlane(gofs, u)];
+      a[u] = par[2 * u];                               // (top, bottom) weight of this lane's column
+    }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        g[u] = grad_out[__builtin_amdgcn_readlane(gofs, j0 + u) + (lane & 31)];
+    for (int j0 = 0; j0 < 64; j0 += 8) {               // (samples past the end of the chunk carry zero weights)
+      if (j0 + 8 < 64) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          gn[u] = gl[__builtin_amdgcn_readlane(gofs, (j0 + 8 + u) & 63)];
+          an[u] = par[2 * ((j0 + 8 + u) & 63)];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);               // keep the requests above ahead of the adds below
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int j = j0 + u;
-        // lanes 0-31 take the left-column weights, 32-63 the right-column ones (bit select, no branch)
-        const float a_top = __int_as_float((__builtin_amdgcn_readlane(__float_as_int(w_top_l), j) & ~rmask) |
-                                           (__builtin_amdgcn_readlane(__float_as_int(w_top_r), j) & rmask));
-        const float a_bot = __int_as_float((__builtin_amdgcn_readlane(__float_as_int(w_bot_l), j) & ~rmask) |
-                                           (__builtin_amdgcn_readlane(__float_as_int(w_bot_r), j) & rmask));
-        float* p = win + __builtin_amdgcn_readlane(off, j) + lane;   // + 32 for the right column
-        const float t0 = p[0], t1 = p[kWin * kCh];
-        p[0] = t0 + a_top * g[u];
-        p[kWin * kCh] = t1 + a_bot * g[u];
-        // (measured and rejected: issuing the reads of two consecutive samples together when their 2x2
-        //  footprints are disjoint -- the wave-uniform test and the extra branch cost more than the shorter
-        //  dependency chain saves: SCA 1.33 -> 1.53 ms, TSA 0.39 -> 0.41 ms)
+        float* p = wl + __builtin_amdgcn_readlane(off, j0 + u);
+        if (kSharedWin) {
+          unsafeAtomicAdd(p, a[u].x * g[u]);
+          unsafeAtomicAdd(p + kWin * kCh, a[u].y * g[u]);
+        } else {
+          const float t0 = p[0], t1 = p[kWin * kCh];
+          p[0] = t0 + a[u].x * g[u];
+          p[kWin * kCh] = t1 + a[u].y * g[u];
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
     }
   }
-  // flush: window line i = (row r, column c) is pixel (ty*8 + r - 1, tx*8 + c - 1)
+  if (kSharedWin) __syncthreads();
+  // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
   const int ch = lane & 31;
   float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
-  for (int i = lane >> 5; i < kWinLines; i += 2) {
+  const int i0 = kSharedWin ? (threadIdx.x >> 5) : (lane >> 5), di = kSharedWin ? 2 * kTWaves : 2;
+  for (int i = i0; i < kWinLines; i += di) {
     const int r = i / kWin, c = i - r * kWin;
     const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
     if (py < 0 || py >= Hl || px < 0 || px >= Wl) continue;
@@ -663,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
 
 // workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks: 4]
 // [chunk table: 4 * max_chunks][records: n_samples].  The level shapes live on the device, so the host
-// sizes the tables from a bound: a level of h x w pixels has (h/8+1)(w/8+1) <= 9hw/64 + 2 tiles.
+// sizes the tables from a bound (bin_plan).
 struct BinPlan {
   int64_t n_samples, nbins_bound, max_chunks, tiles_bound;
   size_t off_chunks, off_desc, off_rec, bytes;
@@ -672,12 +716,13 @@ struct BinPlan {
 inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
   BinPlan p{};
   p.n_samples = (int64_t)B * Nq * H * L * P;
-  p.tiles_bound = ((int64_t)Nv * 9) / 64 + 2 * L + 1;
+  // a level of h x w pixels has (h/k+1)(w/k+1) <= hw/k^2 + (h+w)/k + 1 <= hw (1+k)/k^2 + 2 tiles (h + w <= hw + 1)
+  p.tiles_bound = ((int64_t)Nv * (1 + kTile)) / (kTile * kTile) + 2 * L + 1;
   p.nbins_bound = (int64_t)B * H * p.tiles_bound;
   p.max_chunks = p.n_samples / kChunk + p.nbins_bound;
   p.off_chunks = sizeof(int) * (size_t)p.nbins_bound;
   p.off_desc = p.off_chunks + 16;
-  p.off_rec = p.off_desc + 16 * (size_t)p.max_chunks;
+  p.off_rec = p.off_desc + 32 * (size_t)p.max_chunks;
   p.bytes = p.off_rec + sizeof(int) * (size_t)p.n_samples;
   p.ok = L <= kMaxL && p.n_samples > 0 && p.n_samples < (1ll << 31) &&
          (int64_t)B * Nq * H * kCh < (1ll << 31) && p.nbins_bound < (1ll << 28) &&
@@ -745,7 +790,7 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
                        n_chunks, B, H, L);
     hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), 2 * blds, s, spatial_shapes, sampling_loc,
                        counts, rec, H, Nq, L, P);
-    const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
+    const int tgrid = kSharedWin ? (int)p.max_chunks : (int)((p.max_chunks + kTWaves - 1) / kTWaves);
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
                        Nv, H, L, P);
