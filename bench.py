@@ -55,7 +55,14 @@ def parse():
     ap.add_argument("--no-backbone", action="store_true",
                     help="feed FPN pyramids instead of images (hot path of SURVEY 8a only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-step", action="store_true",
+                    help="also time the oracle port of the WHOLE step on a bounded sample (BEV 50x50; round-2 leg)")
+    ap.add_argument("--extra-configs", default="vidar_1_8_nusc_3future",
+                    help="comma-separated configs timed after the main one in the same run (short records under "
+                         "`configs`); the north star's target sentence names vidar_1_8_nusc_3future")
+    ap.add_argument("--extra-steps", type=int, default=5)
+    ap.add_argument("--extra-warmup", type=int, default=2)
+    ap.add_argument("--cpu-baseline-only", choices=["ops", "step", "full"], help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 16))
     ap.add_argument("--cpu-baseline-timeout", type=int, default=600)
     ap.add_argument("--cpu-baseline-full", action="store_true",
@@ -129,28 +136,153 @@ def _peak_rss_gb():
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
 
 
-def cpu_baseline_subprocess(args):
-    """Run the CPU leg in a child with a hard wall-clock limit so it can never stall the bench."""
+def _once_or_twice(fn):
+    """seconds of fn(): the second of two calls, unless the first already took > 2 s (then that one)"""
+    t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+    if dt > 2.0:
+        return dt
+    t0 = time.perf_counter(); fn()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_ops(threads):
+    """the hot-path ops of SURVEY 8(a) at FULL size on host cores, one row per op --
+    the oracle's pure-PyTorch restatements (MSDA formula, LatentRendering, GT-ray march + CE, gumbel render, naive
+    O(N*M) chamfer) on `threads` torch threads, the reference's own knn_cpu.cpp build (single-threaded by
+    construction) and the OpenMP C restatement of the dvr / dvxlr kernels.  Every input fits in host RAM at
+    full size; the rows take ~20-40 s together.  -> dict(ops=[...], cores=threads)"""
+    from oracle import chamfer as C
+    from oracle import cpu_ops
+    from oracle import dvr as O
+    from oracle import latent_render as LR
+    from oracle import msda as M
+    from vidar_amd.synthetic import dense_rays, msda_operands, ray_set
+    torch.set_num_threads(threads)
+    rows = []
+
+    def add(op, seconds, shape, impl, thr=threads):
+        rows.append(dict(op=op, cpu_ms=round(seconds * 1e3, 2), shape=shape, impl=impl, threads=thr))
+
+    fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
+    formula = "pure-PyTorch MSDA formula (per-level F.grid_sample), the reference's CPU branch restated (oracle/msda.py)"
+    for tag, B, shapes, Nq, P in (("L=1,P=4", 2, [(200, 200)], 40000, 4), ("L=4,P=8", 6, fpn, 10000, 8)):
+        value, sh, lsi, loc, w = msda_operands(0, B, shapes, Nq, P=P)
+        shape = f"B={B} Nv={value.shape[1]} Nq={Nq} L={len(shapes)} P={P}"
+        with torch.no_grad():
+            add(f"msda_fwd[{tag}]", _once_or_twice(lambda: M.msda_grid_sample(value, sh, loc, w)), shape, formula)
+        v, l, ww = value.requires_grad_(), loc.requires_grad_(), w.requires_grad_()
+        out = M.msda_grid_sample(v, sh, l, ww)
+        go = torch.randn_like(out)
+        add(f"msda_bwd[{tag}]", _once_or_twice(lambda: torch.autograd.grad(out, [v, l, ww], go, retain_graph=True)),
+            shape, formula + ", autograd backward")
+        del value, loc, w, v, l, ww, out, go
+    lr_impl = "latent_rendering.py:79-162 restated with torch ops on CPU tensors (oracle/latent_render.py)"
+    occ = torch.randn(1, 200, 200, 16, requires_grad=True)
+    a = torch.randn(1, 200, 200, 16, requires_grad=True)
+    with torch.no_grad():
+        add("lr_prob_fwd", _once_or_twice(lambda: LR.path_prob(occ, 256, 1.0, "sigmoid")), "bev 200x200 x 16 bins, 257 waypoints", lr_impl)
+    p = LR.path_prob(occ, 256, 1.0, "sigmoid")
+    g = torch.randn_like(p)
+    add("lr_prob_bwd", _once_or_twice(lambda: torch.autograd.grad(p, occ, g, retain_graph=True)), "same", lr_impl + ", autograd backward")
+    pd = p.detach().requires_grad_(True)
+    with torch.no_grad():
+        add("lr_gather_fwd", _once_or_twice(lambda: LR.gather(pd, a, 256, 1.0, 1e-3)), "same", lr_impl)
+    f = LR.gather(pd, a, 256, 1.0, 1e-3)
+    add("lr_gather_bwd", _once_or_twice(lambda: torch.autograd.grad(f, [pd, a], g, retain_graph=True)), "same", lr_impl + ", autograd backward")
+    del occ, a, p, pd, f, g
+    sig, origin, points, tindex = ray_set(seed=0, N=1, T=1, rays_per_frame=30000)
+    sigma = torch.randn(1, 16, 200, 200, requires_grad=True)
+    o, pts, ti = (torch.from_numpy(x[0]) for x in (origin, points, tindex))
+    head_impl = "vidar_head_base.py:420-509,:586-592 restated (trilinear grid_sample of 513 waypoints per ray + CE; oracle/head.py)"
+    with torch.no_grad():
+        add("ray_ce_fwd", _once_or_twice(lambda: cpu_ops._ray_ce(sigma, o, pts, ti)), "30000 rays x 513 waypoints, volume 16x200x200", head_impl)
+    ce, _ = cpu_ops._ray_ce(sigma, o, pts, ti)
+    add("ray_ce_bwd", _once_or_twice(lambda: torch.autograd.grad(ce, sigma, torch.ones_like(ce), retain_graph=True)), "same", head_impl + ", autograd backward")
+    dp, dt_ = dense_rays(1, 16, 200, 200)
+    noise = cpu_ops._gumbel_noise(dp.shape[0], 512)
+    gum_impl = "vidar_head_base.py:594-630,:754-773 restated (hard gumbel-softmax hit + straight-through mass; oracle/head.py)"
+    with torch.no_grad():
+        add("ray_gumbel_fwd", _once_or_twice(lambda: cpu_ops._ray_gumbel(sigma, o, dp, dt_, noise)), f"{dp.shape[0]} dense rays x 512 waypoints", gum_impl)
+    d = cpu_ops._ray_gumbel(sigma, o, dp, dt_, noise)
+    add("ray_gumbel_bwd", _once_or_twice(lambda: torch.autograd.grad(d, sigma, torch.ones_like(d), retain_graph=True)), "same", gum_impl + ", autograd backward")
+    del ce, d
+    rng = np.random.default_rng(0)
+    src = torch.from_numpy(rng.uniform(-5, 5, (1, 10000, 3)).astype(np.float32))
+    dst = torch.from_numpy(rng.uniform(-5, 5, (1, 30000, 3)).astype(np.float32))
+    add("knn1_d3_fwd", _once_or_twice(lambda: cpu_ops._knn_points(src, dst)), "training chamfer: 10000 rendered x 30000 GT points, one direction",
+        "naive O(N*M) dense-expand form of mmdet3d chamfer_distance (call site vidar_head_base.py:654)")
+    # evaluation chamfer: the reference's own extension when oracle/_ref travelled with the snapshot
+    a3 = rng.uniform(-50, 50, (1, 30000, 3)).astype(np.float32)
+    b3 = rng.uniform(-50, 50, (1, 30000, 3)).astype(np.float32)
+    try:
+        from oracle import build_ref
+        ref = build_ref.load("ref_chamferdist_C")
+        l3 = torch.tensor([30000])
+        t0 = time.perf_counter()
+        ref.knn_points_idx(torch.from_numpy(a3), torch.from_numpy(b3), l3, l3, 1, -1)
+        add("chamferdist.knn_points_idx[30000x30000]", time.perf_counter() - t0, "evaluation CD, one direction",
+            "the reference's own ext.cpp + knn_cpu.cpp compiled unmodified (oracle/_ref), single-threaded by construction", thr=1)
+    except Exception:
+        t0 = time.perf_counter()
+        C.knn_points_idx(a3, b3)
+        add("chamferdist.knn_points_idx[30000x30000]", time.perf_counter() - t0, "evaluation CD, one direction",
+            "numpy restatement of knn_cpu.cpp:7-58 (oracle/chamfer.py; oracle/_ref not present on this box)", thr=1)
+    O.set_threads(threads)
+    dvr_impl = "plain-C restatement of the kernel bodies, fp64 in the reference's operation order, OpenMP over rays (oracle/dvr_oracle.c)"
+    add("dvxlr.render[M=30000]", _once_or_twice(lambda: O.dvxlr_render(sig, origin, points, tindex)), "30000 rays, volume 16x200x200", dvr_impl)
+    add("dvr.render_forward[M=30000]", _once_or_twice(lambda: O.render_forward(sig, origin, points, tindex, "train")), "same", dvr_impl)
+    add("dvr.render[M=30000]", _once_or_twice(lambda: O.render(sig, origin, points, tindex, "l1")), "same", dvr_impl)
+    return dict(ops=rows, cores=threads)
+
+
+def cpu_baseline_subprocess(args, mode="ops"):
+    """Run a CPU leg in a child with a hard wall-clock limit so it can never stall the bench.
+    mode: "ops" (op-level full-size rows), "step" (bounded whole-step sample), "full" (one full-size step)."""
     import subprocess
-    base = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", "--config", args.config,
+    base = [sys.executable, str(ROOT / "bench.py"), "--cpu-baseline-only", mode, "--config", args.config,
             "--cpu-threads", str(args.cpu_threads)] + (["--no-backbone"] if args.no_backbone else [])
     env = dict(os.environ, OMP_NUM_THREADS=str(args.cpu_threads), MKL_NUM_THREADS=str(args.cpu_threads))
-    note = ""
-    for extra, limit in ((["--cpu-baseline-full"], args.cpu_baseline_timeout), ([], 240)):
-        if extra and not args.cpu_baseline_full:
-            continue
-        try:
-            r = subprocess.run(base + extra, capture_output=True, text=True, timeout=limit, env=env)
-            for line in reversed(r.stdout.strip().splitlines()):
-                if line.startswith("{"):
-                    out = json.loads(line)
-                    if note:
-                        out["sample"] += " (" + note + ")"
-                    return out
-            note += "cpu leg produced no result: " + r.stderr.strip()[-200:] + "; "
-        except subprocess.TimeoutExpired:
-            note += f"cpu leg{' (full size)' if extra else ' (bounded sample)'} exceeded {limit} s and was stopped; "
+    limit = args.cpu_baseline_timeout if mode == "full" else 300
+    try:
+        r = subprocess.run(base, capture_output=True, text=True, timeout=limit, env=env)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        note = "cpu leg produced no result: " + r.stderr.strip()[-200:]
+    except subprocess.TimeoutExpired:
+        note = f"cpu leg ({mode}) exceeded {limit} s and was stopped"
     return dict(value=None, unit="samples/s", cores=args.cpu_threads, kind="port", sample=note)
+
+
+def cpu_baseline_record(args, gpu_ops, steps, kernel_rows):
+    """`cpu_baseline` of the JSON line: op-level full-size CPU rows next to the GPU's own numbers for the same op,
+    and their call-count-weighted sum = a LOWER BOUND on the full-size CPU step (only the 8(a) ops are in it: no
+    GEMMs, no image backbone, no elementwise work) -> `value` = 1 / that bound, an UPPER bound on CPU samples/s."""
+    rec = cpu_baseline_subprocess(args, "ops")
+    if "ops" not in rec:
+        return rec
+    gpu_kernels = {r["kernel"]: r["avg_ms"] for r in (kernel_rows or [])}
+    bound_ms = 0.0
+    for r in rec["ops"]:
+        g = gpu_ops.get(r["op"])
+        if g is not None:
+            r["calls_per_step"] = g["calls"] / steps
+            r["gpu_ms"] = round(g["avg_ms"], 4)
+            bound_ms += r["cpu_ms"] * r["calls_per_step"]
+        elif r["op"] in gpu_kernels:
+            r["calls_per_step"] = 0                      # surface-only / evaluation op: not on the training step
+            r["gpu_ms"] = gpu_kernels[r["op"]]
+        if r.get("gpu_ms"):
+            r["speedup"] = round(r["cpu_ms"] / r["gpu_ms"], 1)
+    out = dict(value=(1e3 / bound_ms) if bound_ms > 0 else None, unit="samples/s", cores=rec["cores"], kind="port",
+               host_cores=os.cpu_count(), step_lower_bound_ms=round(bound_ms, 1), ops=rec["ops"],
+               sample=(f"op-level, FULL size (BEV 200x200, 6 x 30825 px, 30000 rays): each SURVEY 8(a) op's oracle port "
+                       f"timed once on {rec['cores']} threads (knn_cpu: 1), weighted by the GPU step's own launches per "
+                       f"step; their sum ({bound_ms / 1e3:.1f} s) is a LOWER bound on the CPU step -- GEMMs, the image "
+                       f"backbone and elementwise work are not in it -- so `value` is an UPPER bound on CPU samples/s"))
+    if args.cpu_baseline_step or args.cpu_baseline_full:
+        out["whole_step"] = cpu_baseline_subprocess(args, "full" if args.cpu_baseline_full else "step")
+    return out
 
 
 def hip_time(fn, iters=10, warm=2):
@@ -218,38 +350,57 @@ def kernel_rooflines(dev):
     return rows
 
 
-def main():
-    args = parse()
-    if args.cpu_baseline_only:
-        # never drive the host out of memory: cap this child's address space (a full-size CPU step took a box down)
-        try:
-            import resource
-            total = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
-            cap = min(total // 2, (1 << 40) if args.cpu_baseline_full else (48 << 30))
-            resource.setrlimit(resource.RLIMIT_AS, (cap, cap))
-        except (ImportError, ValueError, OSError):
-            pass
-        print(json.dumps(cpu_baseline(args.config, args.cpu_threads, not args.no_backbone,
-                                      reduced=not args.cpu_baseline_full)), flush=True)
-        return
-    from vidar_amd import train as T
-    from vidar_amd._lib import TIMER
-    from vidar_amd.configs import get_config
-    from vidar_amd.synthetic import fpn_features, make_sample
+def timed_steps(step, steps, warmup, grouped, cuda, after_warmup=None, markers=None):
+    """the contract's timing: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier +
+    synchronize on both sides; -> seconds, MAX over ranks (device-agnostic: the gloo test drives it on CPU)"""
+    def sync():
+        if grouped:
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize()
 
-    rank, local, world = T.init_distributed()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    cfg = get_config(args.config, with_backbone=not args.no_backbone)
-    from vidar_amd import gemm_tuning
-    tuning = dict(enabled=False) if args.no_gemm_tuning else gemm_tuning.enable(results_file=args.tunableop_file, rank=rank)
-    torch.manual_seed(1234)                      # identical initial weights on every rank
-    np.random.seed(1000 + rank)
-    model = T.build_model(cfg).to(dev).train()
-    ddp = T.wrap_ddp(model, local)
-    opt = T.build_optimizer(model)
+    for _ in range(warmup):
+        step()
+    if after_warmup is not None:
+        after_warmup()
+    sync()
+    if markers:
+        markers(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if markers:
+        markers(2)
+    if grouped:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if cuda else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    return elapsed
+
+
+def ddp_info(ddp, world):
+    """what the gradient all-reduce moves per step (RCCL over xGMI): DDP's own bucket accounting.  With
+    find_unused_parameters=False torch starts with ONE bucket and rebuilds the buckets after the first step in
+    the order gradients became ready -- `rebuilt_bucket_bytes` is what overlaps with backward from step 2 on."""
+    if not hasattr(ddp, "_get_ddp_logging_data"):
+        return None
+    try:
+        info = ddp._get_ddp_logging_data()
+        ints = lambda key: [int(x) for x in str(info.get(key, "")).split(",") if x.strip()]
+        sizes, rebuilt = ints("bucket_sizes"), ints("rebuilt_bucket_sizes")
+        live = rebuilt or sizes
+        return {"buckets": len(live), "bucket_bytes": live, "allreduce_bytes_per_step": sum(live),
+                "initial_bucket_bytes": sizes, "rebuilt_bucket_bytes": rebuilt,
+                "has_rebuilt_buckets": bool(info.get("has_rebuilt_buckets", 0)), "bucket_cap_mb": 100,
+                "backend": dist.get_backend(), "world_size": world}
+    except Exception as e:                                           # logging only, never fail the bench
+        return {"error": str(e)[:100]}
+
+
+def make_batch(cfg, args, rank, dev):
+    from vidar_amd.synthetic import fpn_features, make_sample
     spg = args.samples_per_gpu
     samples = [make_sample(seed=100 + rank * spg + i, queue_length=cfg["queue_length"],
                            future_frames=cfg["future_frames"], rays_per_frame=args.rays_per_frame,
@@ -261,35 +412,93 @@ def main():
     else:
         batch["img"] = torch.cat([synthetic_images(200 + rank * spg + i, cfg["queue_length"] + 1,
                                                    cfg["num_cams"], cfg["img_hw"], dev) for i in range(spg)])
+    return batch
 
+
+def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers):
+    """build the model of one named config, time `steps` training steps -> dict(elapsed, ops, ddp, cfg)"""
+    from vidar_amd import gemm_tuning
+    from vidar_amd import train as T
+    from vidar_amd._lib import TIMER
+    from vidar_amd._lib import lib as _hip
+    from vidar_amd.configs import get_config
+    cfg = get_config(name, with_backbone=not args.no_backbone)
+    torch.manual_seed(1234)                      # identical initial weights on every rank
+    np.random.seed(1000 + rank)
+    model = T.build_model(cfg).to(dev).train()
+    ddp = T.wrap_ddp(model, local)
+    opt = T.build_optimizer(model)
+    batch = make_batch(cfg, args, rank, dev)
     grouped = dist.is_available() and dist.is_initialized()
 
-    def sync():
-        if grouped:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def after_warmup():
+        # GEMM shapes were tuned (or loaded) during warm-up: freeze the selection, so no rank ever tunes inside
+        # the timed region while the others wait at the all-reduce
+        gemm_tuning.freeze()
+        TIMER.reset()
+        TIMER.enabled = True
 
-    for _ in range(args.warmup):
-        T.train_step(ddp, opt, batch, cfg["grad_clip"])
-    from vidar_amd._lib import lib as _hip
-    TIMER.reset()
-    TIMER.enabled = True
-    sync()
-    _hip().vidar_marker(1, None)                 # delimits the timed region in a rocprofv3 trace
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        T.train_step(ddp, opt, batch, cfg["grad_clip"])
-    sync()
-    elapsed = time.perf_counter() - t0
-    _hip().vidar_marker(2, None)
+    gemm_tuning.thaw()
+    elapsed = timed_steps(lambda: T.train_step(ddp, opt, batch, cfg["grad_clip"]), steps, warmup, grouped, True,
+                          after_warmup=after_warmup,
+                          markers=(lambda k: _hip().vidar_marker(k, None)) if with_markers else None)
     TIMER.enabled = False
-    if grouped:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    ops = TIMER.summary() if rank == 0 else {}
+    info = ddp_info(ddp, world) if grouped else None
+    del batch, ddp, opt, model
+    torch.cuda.empty_cache()
+    return dict(elapsed=elapsed, ops=ops, ddp=info, cfg=cfg)
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        # never drive the host out of memory: cap this child's address space (a full-size CPU step took a box down)
+        try:
+            import resource
+            total = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+            cap = min(total // 2, (1 << 40) if args.cpu_baseline_only == "full" else (64 << 30))
+            resource.setrlimit(resource.RLIMIT_AS, (cap, cap))
+        except (ImportError, ValueError, OSError):
+            pass
+        if args.cpu_baseline_only == "ops":
+            print(json.dumps(cpu_baseline_ops(args.cpu_threads)), flush=True)
+        else:
+            print(json.dumps(cpu_baseline(args.config, args.cpu_threads, not args.no_backbone,
+                                          reduced=args.cpu_baseline_only == "step")), flush=True)
+        return
+    from vidar_amd import gemm_tuning
+    from vidar_amd import train as T
+
+    rank, local, world = T.init_distributed()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    tuning = dict(enabled=False) if args.no_gemm_tuning else gemm_tuning.enable(results_file=args.tunableop_file, rank=rank)
+    grouped = dist.is_available() and dist.is_initialized()
+    spg = args.samples_per_gpu
+
+    main_run = run_config(args.config, args, rank, local, world, dev, args.steps, args.warmup, with_markers=True)
+    elapsed, ops, cfg = main_run["elapsed"], main_run["ops"], main_run["cfg"]
+    extras = []
+    for name in [c for c in args.extra_configs.split(",") if c and c != args.config]:
+        r = run_config(name, args, rank, local, world, dev, args.extra_steps, args.extra_warmup, with_markers=False)
+        rec = {"config": name, "value": world * spg * args.extra_steps / r["elapsed"], "unit": "samples/s",
+               "ms_per_step": r["elapsed"] / args.extra_steps * 1e3, "steps": args.extra_steps,
+               "warmup": args.extra_warmup, "n_gpus": world, "global_batch": world * spg}
+        if r["ops"]:
+            dn, dv = max(((k, v) for k, v in r["ops"].items() if not k.startswith(("dcn_", "affine_act"))),
+                         key=lambda kv: kv[1]["total_ms"])
+            ach = dv["bytes_per_call"] / (dv["avg_ms"] * 1e-3) / 1e9
+            rec["roofline"] = {"bound": "hbm", "kernel": dn, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBPS, "avg_ms": dv["avg_ms"],
+                               "launches_per_step": dv["calls"] / args.extra_steps}
+        if r["ddp"]:
+            rec["ddp"] = r["ddp"]
+        extras.append(rec)
 
     if rank == 0:
-        ops = TIMER.summary()
         if args.op_table:
             for k, v in sorted(ops.items(), key=lambda kv: -kv[1]["total_ms"]):
                 gb = v["bytes_per_call"] / v["avg_ms"] / 1e6 if v["avg_ms"] > 0 else 0
@@ -320,28 +529,21 @@ def main():
                          "traffic": pmc_traffic(dom_name)[0], "traffic_source": pmc_traffic(dom_name)[1],
                          "avg_ms": dom["avg_ms"], "launches_per_step": dom["calls"] / args.steps,
                          "ms_per_step": dom["total_ms"] / args.steps, "hip_ops_ms_per_step": hip_ms},
-            "gemm_tuning": dict(tuning, solutions=gemm_tuning.count_results() if tuning.get("enabled") else 0),
+            "gemm_tuning": dict(tuning, solutions=gemm_tuning.count_results() if tuning.get("enabled") else 0,
+                                frozen_after_warmup=bool(tuning.get("enabled"))),
             "roofline_step_dominant": {"bound": "hbm", "kernel": all_name, "achieved": all_ach, "peak": HBM_PEAK_GBPS,
                                        "unit": "GB/s", "frac": all_ach / HBM_PEAK_GBPS, "avg_ms": all_dom["avg_ms"],
                                        "launches_per_step": all_dom["calls"] / args.steps,
                                        "ms_per_step": all_dom["total_ms"] / args.steps},
         }
-        if grouped and hasattr(ddp, "_get_ddp_logging_data"):
-            # what the gradient all-reduce moves per step (RCCL over xGMI): DDP's own bucket accounting
-            try:
-                info = ddp._get_ddp_logging_data()
-                sizes = [int(x) for x in str(info.get("bucket_sizes", "")).split(",") if x.strip()]
-                out["ddp"] = {"buckets": len(sizes), "bucket_bytes": sizes, "allreduce_bytes_per_step": sum(sizes),
-                              "bucket_cap_mb": 100, "backend": dist.get_backend(), "world_size": world}
-            except Exception as e:                                   # logging only, never fail the bench
-                out["ddp"] = {"error": str(e)[:100]}
+        if extras:
+            out["configs"] = extras
+        if main_run["ddp"]:
+            out["ddp"] = main_run["ddp"]
         if world == 1 and not args.no_kernel_rooflines and not grouped:
-            del batch, ddp, opt, model
-            torch.cuda.empty_cache()
             out["roofline_kernels"] = kernel_rooflines(dev)
         if world == 1 and not args.no_cpu_baseline and not grouped:
-            out["cpu_baseline"] = cpu_baseline_subprocess(args)
-            out["cpu_baseline"]["host_cores"] = os.cpu_count()
+            out["cpu_baseline"] = cpu_baseline_record(args, ops, args.steps, out.get("roofline_kernels"))
         print(json.dumps(out), flush=True)
     if grouped:
         dist.barrier()

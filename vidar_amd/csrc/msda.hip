@@ -375,25 +375,27 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
 // flushes the non-zero window lines with one atomic per line: ~2-3 M requests instead of 61 M.
 // grad_loc / grad_w come from a gather kernel shaped like the forward (no atomics at all).
 // ---------------------------------------------------------------------------------------------
+// Two accumulate kernels (VIDAR_MSDA_ACC): 1 = the destination window of a chunk lives in REGISTERS (tile edge 4:
+// 5x5 corner pixels = 25 accumulators per lane, indexed with the wave-uniform window offset through the VGPR
+// index mode) -- no LDS read-modify-write chain at all; 0 = round 2's private LDS window per wave (tile edge 8).
+#ifndef VIDAR_MSDA_ACC
+#define VIDAR_MSDA_ACC 1
+#endif
 #ifndef VIDAR_MSDA_TILE_SHIFT
-#define VIDAR_MSDA_TILE_SHIFT 3
+#define VIDAR_MSDA_TILE_SHIFT (VIDAR_MSDA_ACC ? 2 : 3)
 #endif
 constexpr int kTileShift = VIDAR_MSDA_TILE_SHIFT;
 constexpr int kTile = 1 << kTileShift;         // tile edge (top-left corner pixels)
 constexpr int kWin = kTile + 1;                // window edge (corner pixels)
-constexpr int kWinLines = kWin * kWin;         // 81 lines of 32 floats
-#ifndef VIDAR_MSDA_SHARED_WIN
-#define VIDAR_MSDA_SHARED_WIN 1
-#endif
-// 1: the 4 waves of a workgroup accumulate ONE window with ds_add_f32 (no read-modify-write chain, one flush per
-//    4096 samples); 0: a private window per wave, plain read-modify-writes (round 2)
-constexpr bool kSharedWin = VIDAR_MSDA_SHARED_WIN != 0;
+constexpr int kWinLines = kWin * kWin;         // window lines of 32 floats
+constexpr bool kRegWin = VIDAR_MSDA_ACC != 0;
+static_assert(!kRegWin || kWinLines <= 32, "the register window holds at most 32 lines");
 #ifndef VIDAR_MSDA_CHUNK
-#define VIDAR_MSDA_CHUNK (VIDAR_MSDA_SHARED_WIN ? 4096 : 1024)
+#define VIDAR_MSDA_CHUNK 1024
 #endif
-constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor (tuning sweep: tools/tune_msda_tile.sh)
+constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor = per wave (tuning sweep: tools/tune_msda_tile.sh)
 constexpr int kMaxL = 16;                      // levels supported by the binned path
-constexpr int kTWaves = 4;                     // waves per workgroup of the tile kernel
+constexpr int kTWaves = 4;                     // waves (= chunks) per workgroup of the accumulate kernel
 
 struct LevelTab {
   int Hl[kMaxL], Wl[kMaxL], ntx[kMaxL], toff[kMaxL];
@@ -437,7 +439,7 @@ template <bool FILL>
 __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
     const int64_t* __restrict__ shapes, const float* __restrict__ loc, int* __restrict__ counts,
     int* __restrict__ rec, int H, int Nq, int L, int P) {
-  extern __shared__ int s_hist[];              // [ntl] counts, then (FILL) [ntl] base slots
+  extern __shared__ int s_hist[];              // [ntl] counts; (FILL) then the per-tile record cursors
   __shared__ LevelTab t;
   build_tab(t, shapes, L);
   const int plane = blockIdx.y;                // (b * H + h) * L + l
@@ -446,7 +448,6 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
   const int q0 = blockIdx.x * kBinQ, nq = min(kBinQ, Nq - q0);
   const int n = nq * P;                        // samples of this workgroup
   const int LP = L * P;
-  int* s_base = s_hist + ntl;
   for (int i = threadIdx.x; i < ntl; i += kThreads) s_hist[i] = 0;
   __syncthreads();
   const int64_t gbin0 = ((int64_t)b * t.T + t.toff[l]) * H + h;    // bin = gbin0 + tile * H
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
     // reserve a run of record slots per touched tile (the cursor was initialised with the bin starts)
     for (int i = threadIdx.x; i < ntl; i += kThreads) {
       const int c = s_hist[i];
-      if (c) { s_base[i] = atomicAdd(counts + gbin0 + (int64_t)i * H, c); s_hist[i] = 0; }
+      if (c) s_hist[i] = atomicAdd(counts + gbin0 + (int64_t)i * H, c);    // the LDS counter becomes the cursor
     }
     __syncthreads();
 #pragma unroll
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
       const int tl = tile_of[u];
       if (tl >= 0) {
         const int ql = i / P, p = i - ql * P;
-        rec[s_base[tl] + atomicAdd(s_hist + tl, 1)] =
+        rec[atomicAdd(s_hist + tl, 1)] =
             (int)((((int64_t)b * Nq + q0 + ql) * H + h) * LP + l * P + p);
       }
     }
@@ -501,79 +502,98 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
     const int64_t* __restrict__ shapes, int* __restrict__ counts, int4* __restrict__ desc,
     int* __restrict__ n_chunks, int B, int H, int L) {
   __shared__ LevelTab t;
-  __shared__ int s_sum[kScanThreads], s_chk[kScanThreads];
+  __shared__ int s_wsum[kScanThreads / 64], s_wchk[kScanThreads / 64];
   build_tab(t, shapes, L);
   const int nbins = B * t.T * H;
-  const int per = (nbins + kScanThreads - 1) / kScanThreads;
-  const int r0 = min(nbins, (int)threadIdx.x * per), r1 = min(nbins, r0 + per);
-  int cs = 0, cc = 0;
-  for (int b = r0; b < r1; ++b) { const int c = counts[b]; cs += c; cc += (c + kChunk - 1) / kChunk; }
-  s_sum[threadIdx.x] = cs; s_chk[threadIdx.x] = cc;
-  __syncthreads();
-  for (int d = 1; d < kScanThreads; d <<= 1) {        // Hillis-Steele inclusive scan
-    int a = 0, c = 0;
-    if ((int)threadIdx.x >= d) { a = s_sum[threadIdx.x - d]; c = s_chk[threadIdx.x - d]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry_s = 0, carry_k = 0;                        // records / chunks before this slab of 1024 bins
+  for (int base = 0; base < nbins; base += kScanThreads) {
+    const int bin = base + threadIdx.x;
+    const int c = bin < nbins ? counts[bin] : 0;       // coalesced
+    const int k = (c + kChunk - 1) / kChunk;
+    int xs = c, xk = k;                                // inclusive wave scans
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int ts = __shfl_up(xs, d, 64), tk = __shfl_up(xk, d, 64);
+      if (lane >= d) { xs += ts; xk += tk; }
+    }
+    if (lane == 63) { s_wsum[wave] = xs; s_wchk[wave] = xk; }
     __syncthreads();
-    s_sum[threadIdx.x] += a; s_chk[threadIdx.x] += c;
-    __syncthreads();
-  }
-  int s = s_sum[threadIdx.x] - cs, k = s_chk[threadIdx.x] - cc;
-  for (int bin = r0; bin < r1; ++bin) {
-    const int c = counts[bin];
-    counts[bin] = s;
-    if (c) {
-      const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
-      int l = 0;
-      while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
-      const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
-      for (int i = 0; i < c; i += kChunk) {
-        desc[2 * k] = make_int4(s + i, min(kChunk, c - i), l, b);
-        desc[2 * k + 1] = make_int4(h, ty, tx, 0);
-        ++k;
+    int ws = 0, wk = 0, tot_s = 0, tot_k = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; ++w) {
+      const int a = s_wsum[w], q = s_wchk[w];
+      tot_s += a; tot_k += q;
+      if (w < wave) { ws += a; wk += q; }
+    }
+    if (bin < nbins) {
+      const int s = carry_s + ws + xs - c;
+      int kk = carry_k + wk + xk - k;
+      counts[bin] = s;
+      if (c) {
+        const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
+        int l = 0;
+        while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
+        const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
+        for (int i = 0; i < c; i += kChunk) {
+          desc[2 * kk] = make_int4(s + i, min(kChunk, c - i), l, b);
+          desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
+          ++kk;
+        }
       }
     }
-    s += c;
+    carry_s += tot_s; carry_k += tot_k;
+    __syncthreads();
   }
-  if (threadIdx.x == kScanThreads - 1) *n_chunks = s_chk[threadIdx.x];
+  if (threadIdx.x == 0) *n_chunks = carry_k;
 }
 
-// Accumulate kernel.  One chunk (<= kChunk records of one destination tile) per workgroup of 4 waves.
+// Accumulate kernel.  One chunk (<= kChunk records of one destination tile) per wave.
 // All 64 lanes of a wave work on ONE sample: lanes 0-31 own the 32 channels of the left corner column,
-// lanes 32-63 the right column; the top row and the bottom row are two LDS operations.  Round 2 spent
-// ~18 VALU instructions per sample on handing the per-sample scalars to the lanes (readlane + select
-// chains) and was VALU-issue bound at 0.5 ms for the 15 M samples of SpatialCrossAttention.  Now lane k
-// of a 64-sample batch prepares sample k and parks its four corner weights in LDS as two 8-byte records
-// (left column, right column); in the sample loop every lane picks its column's (top, bottom) pair with ONE
-// ds_read_b64 whose address does not depend on the sample (immediate offsets), the window offset and the
-// grad_out line travel by v_readlane (2 per sample), and the window is shared by the workgroup's waves
-// and accumulated with ds_add_f32 (no return value -> no read-modify-write dependency chain).
+// lanes 32-63 the right column; top row and bottom row are two accumulations.  Round 2 kept the window in LDS
+// (plain read-modify-writes, 10 KB per wave): a dependent ds_read -> fma -> ds_write chain per sample with 3-4
+// waves per SIMD, 0.62 ms for the 15 M samples of SpatialCrossAttention no matter how few VALU instructions
+// the per-sample scalar hand-off takes (18 -> 7 measured: 1.28 -> 1.23 ms), and ds_add_f32 on a shared window
+// is 8x slower still (10 ms: LDS float atomics retire at ~100 clocks per instruction).  So the window moved
+// into registers: with a 4x4 tile it is 5x5 lines = 25 accumulators per lane (lanes 32-63 hold the window
+// shifted by one column), addressed by the wave-uniform window offset through the VGPR index mode
+// (s_set_gpr_idx_on): v_mov out, v_fmac, v_mov in -- dependent VALU operations instead of LDS round trips.
+// Lane k of a 64-sample batch prepares sample k and parks its four corner weights in LDS as two 8-byte records
+// (left column, right column); in the sample loop every lane picks its column's (top, bottom) pair with one
+// ds_read_b64, the window offset and the grad_out line travel by v_readlane.
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+__device__ __forceinline__ float go_line(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+}
+
+template <bool REG>
 __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
     const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
-    int H, int L, int P) {
-  __shared__ float s_win[kSharedWin ? 1 : kTWaves][kWinLines * kCh];
+    int H, int L, int P, int go_bytes) {
+  __shared__ float s_win[REG ? 1 : kTWaves][REG ? 1 : kWinLines * kCh];
   __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, bottom-left, top-right, bottom-right}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int chunk = kSharedWin ? blockIdx.x : blockIdx.x * kTWaves + wave;
-  if (chunk >= *n_chunks) return;                      // workgroup-uniform (shared window) / wave-uniform
+  const int chunk = blockIdx.x * kTWaves + wave;
+  if (chunk >= *n_chunks) return;                      // wave-uniform
   const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
   const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
   const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-  float* win = s_win[kSharedWin ? 0 : wave];
-  if (kSharedWin) {
-    for (int i = threadIdx.x; i < kWinLines * kCh; i += 64 * kTWaves) win[i] = 0.f;
-    __syncthreads();
-  } else {
+  float* win = s_win[REG ? 0 : wave];
+  f32x32 acc = 0.f;
+  if (!REG)
     for (int i = lane; i < kWinLines * kCh; i += 64) win[i] = 0.f;
-  }
   const int LP = L * P;
   const float2* par = reinterpret_cast<const float2*>(&s_par[wave][0]) + (lane >> 5);
   float* wl = win + lane;
-  const float* gl = grad_out + (lane & 31);
-  const int step = kSharedWin ? 64 * kTWaves : 64;
-  for (int base = kSharedWin ? wave * 64 : 0; base < n; base += step) {
-    // lane k prepares sample base+k: window offset of its top-left corner, the four corner weights
+  const int ch = lane & 31, ch4 = ch * 4;
+  // grad_out lines are fetched with buffer loads: per-lane byte offset (channel) in a VGPR, the sample's line offset
+  // in an SGPR -- no vector address arithmetic per sample
+  const __amdgpu_buffer_rsrc_t go_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
+  for (int base = 0; base < n; base += 64) {
+    // lane k prepares sample base+k: window line of its top-left corner, the four corner weights
     // (times the attention weight) and the offset of its grad_out line
     const bool valid = base + lane < n;
     const int s = rec[s0 + (valid ? base + lane : 0)];
@@ -585,16 +605,17 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const float hh = (1.f - lh) * aw, lha = lh * aw;
     __builtin_amdgcn_wave_barrier();                   // the previous batch's reads of s_par are done (in-order LDS)
     s_par[wave][lane] = make_float4(hh * (1.f - lw), lha * (1.f - lw), hh * lw, lha * lw);
-    const int off = (min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1)) * kCh;
-    const int gofs = (s / LP) * kCh;
+    const int line = min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1);
+    // one word per sample for the v_readlane hand-off: byte offset of its grad_out line (a multiple of 128) | window line
+    const int pack = ((s / LP) * (kCh * 4)) | line;
     __builtin_amdgcn_wave_barrier();
     // groups of 8 samples, software-pipelined by hand: the weight pairs and grad_out lines of group k+1
-    // are requested before the LDS adds of group k (the compiler keeps LDS reads behind LDS atomics)
+    // are requested before the accumulation of group k
     float g[8], gn[8];
     float2 a[8], an[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      g[u] = gl[__builtin_amdgcn_readlane(gofs, u)];
+      g[u] = go_line(go_rsrc, ch4, __builtin_amdgcn_readlane(pack, u) & ~127);
       a[u] = par[2 * u];                               // (top, bottom) weight of this lane's column
     }
 #pragma unroll
@@ -602,18 +623,19 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
       if (j0 + 8 < 64) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          gn[u] = gl[__builtin_amdgcn_readlane(gofs, (j0 + 8 + u) & 63)];
+          gn[u] = go_line(go_rsrc, ch4, __builtin_amdgcn_readlane(pack, (j0 + 8 + u) & 63) & ~127);
           an[u] = par[2 * ((j0 + 8 + u) & 63)];
         }
       }
-      __builtin_amdgcn_sched_barrier(0);               // keep the requests above ahead of the adds below
+      __builtin_amdgcn_sched_barrier(0);               // keep the requests above ahead of the accumulation below
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        float* p = wl + __builtin_amdgcn_readlane(off, j0 + u);
-        if (kSharedWin) {
-          unsafeAtomicAdd(p, a[u].x * g[u]);
-          unsafeAtomicAdd(p + kWin * kCh, a[u].y * g[u]);
+        const int i = __builtin_amdgcn_readlane(pack, j0 + u) & 127;
+        if (REG) {
+          acc[i] += a[u].x * g[u];
+          acc[i + kWin] += a[u].y * g[u];
         } else {
+          float* p = wl + i * kCh;
           const float t0 = p[0], t1 = p[kWin * kCh];
           p[0] = t0 + a[u].x * g[u];
           p[kWin * kCh] = t1 + a[u].y * g[u];
@@ -623,17 +645,27 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
       for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
     }
   }
-  if (kSharedWin) __syncthreads();
   // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
-  const int ch = lane & 31;
   float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
-  const int i0 = kSharedWin ? (threadIdx.x >> 5) : (lane >> 5), di = kSharedWin ? 2 * kTWaves : 2;
-  for (int i = i0; i < kWinLines; i += di) {
-    const int r = i / kWin, c = i - r * kWin;
-    const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
-    if (py < 0 || py >= Hl || px < 0 || px >= Wl) continue;
-    const float v = win[i * kCh + ch];
-    if (v != 0.f) unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
+  if (REG) {
+    // register i of lanes 0-31 is window line i, of lanes 32-63 the line one column to the right
+    const int right = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < kWinLines; ++i) {
+      const int r = i / kWin, c = i % kWin + right;
+      const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
+      const float v = acc[i];
+      if (v != 0.f && py >= 0 && py < Hl && px >= 0 && px < Wl && c < kWin)
+        unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
+    }
+  } else {
+    for (int i = lane >> 5; i < kWinLines; i += 2) {
+      const int r = i / kWin, c = i - r * kWin;
+      const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
+      if (py < 0 || py >= Hl || px < 0 || px >= Wl) continue;
+      const float v = win[i * kCh + ch];
+      if (v != 0.f) unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
+    }
   }
 }
 
@@ -725,7 +757,7 @@ inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
   p.off_rec = p.off_desc + 32 * (size_t)p.max_chunks;
   p.bytes = p.off_rec + sizeof(int) * (size_t)p.n_samples;
   p.ok = L <= kMaxL && p.n_samples > 0 && p.n_samples < (1ll << 31) &&
-         (int64_t)B * Nq * H * kCh < (1ll << 31) && p.nbins_bound < (1ll << 28) &&
+         (int64_t)B * Nq * H * kCh * 4 < (1ll << 31) && p.nbins_bound < (1ll << 28) &&
          p.tiles_bound <= kMaxTilesLds && (int64_t)B * H * L < 65536;
   return p;
 }
@@ -788,12 +820,12 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
                        counts, rec, H, Nq, L, P);
     hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, spatial_shapes, counts, desc,
                        n_chunks, B, H, L);
-    hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), 2 * blds, s, spatial_shapes, sampling_loc,
+    hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
                        counts, rec, H, Nq, L, P);
-    const int tgrid = kSharedWin ? (int)p.max_chunks : (int)((p.max_chunks + kTWaves - 1) / kTWaves);
-    hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
+    const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
+    hipLaunchKernelGGL(msda_bwd_tile_kernel<kRegWin>, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
-                       Nv, H, L, P);
+                       Nv, H, L, P, (int)(n_items * kCh * 4));
     const int nblocks = (int)((n_items + kItems - 1) / kItems);
     const int grid = ((nblocks + 7) / 8) * 8;
     const size_t lds = sizeof(float) * (kItems * L * P * 3 + kItems);

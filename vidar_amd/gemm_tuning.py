@@ -38,6 +38,26 @@ def enable(tune_missing: bool = True, results_file=None, rank: int = 0, max_tuni
                 results_file=str(out))
 
 
+def freeze():
+    """stop TUNING new shapes (tuned / shipped solutions stay in use).  Call after warm-up: under DDP a rank that
+    meets a new GEMM shape mid-training (e.g. a new padded SpatialCrossAttention length) would otherwise spend
+    seconds tuning while the other ranks wait at the gradient all-reduce.  No-op without a GPU."""
+    import torch
+    if torch.cuda.is_available():
+        import torch.cuda.tunable as tn
+        if tn.is_enabled():
+            tn.tuning_enable(False)
+
+
+def thaw():
+    """allow tuning again (warm-up of another model / config); no-op unless TunableOp was enabled"""
+    import torch
+    if torch.cuda.is_available():
+        import torch.cuda.tunable as tn
+        if tn.is_enabled():
+            tn.tuning_enable(True)
+
+
 def count_results():
     import torch.cuda.tunable as tn
     try:
