@@ -68,3 +68,81 @@ def test_gemm_tuning_is_a_no_op_without_a_gpu_and_ships_validated_solutions():
     assert any("gfx950" in v for v in validators)
     assert len(entries) > 100 and all(len(e) == 4 and e[0].startswith("Gemm") and float(e[3]) > 0 for e in entries)
     assert len({(e[0], e[1]) for e in entries}) == len(entries)          # one solution per (op, shape)
+
+
+def test_cpu_baseline_record_weights_op_rows_by_the_gpu_steps_launch_counts(monkeypatch):
+    """`cpu_baseline` = op-level full-size CPU rows x the GPU step's own launches per step (a lower bound on the CPU
+    step); surface-only ops (dvr family, evaluation KNN) are listed with calls_per_step 0 and stay out of the sum."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    child = dict(cores=16, ops=[dict(op="msda_fwd[L=4,P=8]", cpu_ms=6000.0, shape="", impl="", threads=16),
+                                dict(op="ray_ce_bwd", cpu_ms=800.0, shape="", impl="", threads=16),
+                                dict(op="dvxlr.render[M=30000]", cpu_ms=1500.0, shape="", impl="", threads=16),
+                                dict(op="not measured on the GPU", cpu_ms=1.0, shape="", impl="", threads=16)])
+    monkeypatch.setattr(bench, "cpu_baseline_subprocess", lambda args, mode="ops": dict(child))
+    args = type("A", (), dict(cpu_baseline_step=False, cpu_baseline_full=False, cpu_threads=16))()
+    gpu_ops = {"msda_fwd[L=4,P=8]": dict(calls=60, avg_ms=0.3, total_ms=18.0, bytes_per_call=1),
+               "ray_ce_bwd": dict(calls=10, avg_ms=0.9, total_ms=9.0, bytes_per_call=1)}
+    rec = bench.cpu_baseline_record(args, gpu_ops, steps=2, kernel_rows=[dict(kernel="dvxlr.render[M=30000]", avg_ms=0.25)])
+    assert rec["kind"] == "port" and rec["cores"] == 16 and rec["unit"] == "samples/s"
+    assert rec["step_lower_bound_ms"] == 6000.0 * 30 + 800.0 * 5
+    assert abs(rec["value"] - 1e3 / rec["step_lower_bound_ms"]) < 1e-12
+    rows = {r["op"]: r for r in rec["ops"]}
+    assert rows["msda_fwd[L=4,P=8]"]["speedup"] == 20000.0 and rows["dvxlr.render[M=30000]"]["calls_per_step"] == 0
+    assert "speedup" not in rows["not measured on the GPU"]
+    json.dumps(rec)
+
+
+def _bench_group_worker(rank, world, port, out):
+    """bench.py's grouped code path on CPU: barrier + synchronize bracket, MAX all-reduce of the elapsed time, the
+    `ddp` block (initial and rebuilt buckets), rank-seeded samples -- so the first real multi-GPU run cannot die on
+    plumbing (the GPU path differs only in the device the tensors live on)."""
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import time
+    import numpy as np
+    import torch.distributed as dist
+    import bench
+    from oracle import cpu_ops
+    from test_plugin_cpu import _small_batch
+    from vidar_amd import train as T
+    torch.set_num_threads(2)
+    r, l, w = T.init_distributed()
+    torch.manual_seed(1234); np.random.seed(1000 + rank)
+    cfg, batch = _small_batch("vidar_1_8_nusc_1future", seed=100 + rank)
+    model = T.build_model(cfg).train()
+    ddp = T.wrap_ddp(model, l)
+    opt = T.build_optimizer(model)
+    calls = []
+
+    def step():
+        if rank == 1:
+            time.sleep(0.05)                       # the slow rank sets the time every rank reports
+        with cpu_ops.patched():
+            T.train_step(ddp, opt, batch)
+        calls.append(1)
+
+    marks = []
+    elapsed = bench.timed_steps(step, steps=2, warmup=1, grouped=True, cuda=False,
+                                after_warmup=lambda: marks.append("warm"), markers=marks.append)
+    info = bench.ddp_info(ddp, w)
+    out[rank] = dict(elapsed=elapsed, calls=len(calls), marks=marks, info=info,
+                     first=float(batch["gt_points"][0][0, 0]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_grouped_timing_and_ddp_block_two_ranks_gloo():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = mp.Manager().dict()
+    mp.spawn(_bench_group_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert a["calls"] == b["calls"] == 3 and a["marks"] == ["warm", 1, 2]
+    assert a["elapsed"] == b["elapsed"] and a["elapsed"] >= 0.1          # MAX over ranks (rank 1 sleeps 2 x 50 ms)
+    assert a["first"] != b["first"], "ranks must time different samples"
+    for i in (a["info"], b["info"]):
+        assert i["world_size"] == 2 and i["backend"] == "gloo" and i["allreduce_bytes_per_step"] > 0
+        assert i["has_rebuilt_buckets"] and sum(i["rebuilt_bucket_bytes"]) == sum(i["initial_bucket_bytes"])

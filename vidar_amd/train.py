@@ -130,10 +130,13 @@ class CosineWithWarmup:
 
 
 def fit(model, optimizer, batches, iters, scheduler=None, max_norm=35.0, log_every=50, log_path=None,
-        ckpt_path=None, ckpt_every=0, rank=0, start_iter=0):
+        ckpt_path=None, ckpt_every=0, rank=0, start_iter=0, freeze_gemm_tuning_after=20):
     """Thin training loop (the reference delegates this to mmcv's EpochBasedRunner + hooks, which are
     out of scope): `batches` is any iterable of forward_train kwargs; JSON-lines log of the loss
-    terms and samples/s; optional periodic checkpoints in the mmcv dictionary layout."""
+    terms and samples/s; optional periodic checkpoints in the mmcv dictionary layout.  After
+    `freeze_gemm_tuning_after` iterations TunableOp stops tuning new GEMM shapes (gemm_tuning.freeze):
+    a rank that met a new padded SpatialCrossAttention length later would otherwise tune for seconds
+    while the other ranks wait at the gradient all-reduce."""
     import json
     import time
     from .checkpoint import save_checkpoint
@@ -146,6 +149,9 @@ def fit(model, optimizer, batches, iters, scheduler=None, max_norm=35.0, log_eve
                 scheduler.step()
             total, parts = train_step(model, optimizer, batch, max_norm)
             it += 1
+            if it - start_iter == freeze_gemm_tuning_after:
+                from . import gemm_tuning
+                gemm_tuning.freeze()
             if log is not None and (it % log_every == 0 or it == iters):
                 rec = dict(iter=it, lr=optimizer.param_groups[0]["lr"], loss=float(total),
                            samples_per_s_per_rank=(it - start_iter) / (time.perf_counter() - t0),
