@@ -143,6 +143,17 @@ def bench_msda(which):
             report(f"msda_bwd {name} binned={binned}", ms, fwd_bytes + 4 * (B * Nq * 256 + B * Nv * 256 + B * Nq * 8 * L * P * 3))
 
 
+def bench_msda_sca(which):
+    """SpatialCrossAttention shape only, few iterations: the driver of the PMC passes (tools/pmc_pass.sh)"""
+    from vidar_amd.synthetic import msda_operands
+    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_forward, _msda_backward
+    fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
+    value, sh, lsi, loc, w = msda_operands(0, 6, fpn, 10000, P=8, device="cuda")
+    go = torch.randn(6, 10000, 256, device="cuda")
+    report("msda_fwd SCA", timeit(lambda: _msda_forward(value, sh, lsi, loc, w), warm=1, it=3))
+    report("msda_bwd SCA binned=True", timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=True), warm=1, it=3))
+
+
 def bench_dcn(which):
     """DCNv2 sampling kernels at the two backbone shapes (stage 3: 256 ch 58x100, stage 4: 512 ch 29x50),
     12 images = the frames that carry gradients."""

@@ -1,16 +1,18 @@
 #!/bin/bash
 # One rocprofv3 PMC pass per counter (separate passes, kernel-trace only -- never combined with sys/hip traces):
-#   tools/pmc_pass.sh <outdir> "<counter> <counter> ..." <command...>
-# Writes <outdir>/pmc_<counter>.csv = "kernel,counter,dispatches,mean,min,max" per kernel of this library
+#   tools/pmc_pass.sh <outdir> "<counter> <counter,counter,...> ..." <command...>
+# (a comma-separated group is collected in ONE pass)
+# Writes <outdir>/pmc_<first counter of the group>.csv = "kernel,counter,dispatches,mean,min,max" per kernel of this library
 # (and of the calibration micro-benchmark).
 set -u
 out=$(mkdir -p "$1" && cd "$1" && pwd); shift
 counters=$1; shift
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-for c in $counters; do
+for grp in $counters; do
+  c=${grp%%,*}
   rm -rf /tmp/pmc_$c
-  ( cd "$root" && timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o run -- "$@" ) > /tmp/pmc_$c.log 2>&1 < /dev/null
+  ( cd "$root" && timeout 300 rocprofv3 --pmc ${grp//,/ } --output-format csv -d /tmp/pmc_$c -o run -- "$@" ) > /tmp/pmc_$c.log 2>&1 < /dev/null
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python - "$f" "$out/pmc_$c.csv" <<'PY'

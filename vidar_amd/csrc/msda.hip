@@ -136,16 +136,51 @@ __device__ __forceinline__ int64_t raw_index(int64_t item, int lp, int H, int Nq
   return ((((b * Nq + q) * H + h) * Qn + qn) * LP) + lp;
 }
 
-// stage operands of `nvalid` items starting at item0 into s_loc [n][LP*2] / s_w [n][LP]
+// ---------------------------------------------------------------------------------------------
+// Gather kernels (forward, and grad_loc / grad_w of the backward).  A workgroup owns 32 consecutive
+// (b, q, head) items; item = 8 adjacent lanes x float4 = one 128-byte line per corner fetch.  Round 2 let
+// each of the 8 lanes of an item redo the whole corner arithmetic of every sample (~75 VALU instructions
+// per sample, 8-fold redundant, 4 loads in flight per wave).  Now the corner arithmetic is done ONCE per
+// sample, by one thread, into a 32-byte LDS record; the gather loop of an item then is two (forward) or one
+// (backward) broadcast ds_read_b128 + four `global_load_dwordx4 v, voffset, s[value]` per sample, unrolled
+// by 4 (16 lines in flight per wave).  Records of item k are skewed by k records so that the 8 items of a
+// wave read from 8 different bank groups.
+//   forward record : {w00, w01, w10, w11 (bilinear x attention weight, 0 outside), o00, o01, o10, o11}
+//   backward record: {lh, lw, w, meta (bit 0-3 corner validity, 4.. level, -1: sample outside),
+//                     o00, o01, o10, o11 -> overwritten by the four corner dot products}
+//   o = BYTE offset of the corner's 128-byte line of this item's head from `value` (32-bit: the host
+//   checks B*Nv*H*32*4 < 2^32); an invalid corner points at a valid line and carries weight / mask 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRecF = 8;                    // floats per sample record
+constexpr int kGLv = 16;                    // levels supported by the gather kernels' level table
+
+__device__ __forceinline__ int rec_at(int it, int lp, int LP) { return (it * (LP + 1) + lp) * kRecF; }
+inline size_t rec_lds_bytes(int LP) { return sizeof(float) * (size_t)kItems * (LP + 1) * kRecF; }
+
+struct GLevels { int Hl[kGLv], Wl[kGLv], start[kGLv]; };
+
+__device__ __forceinline__ void load_levels(GLevels& t, const int64_t* __restrict__ shapes,
+                                            const int64_t* __restrict__ lsi, int L) {
+  if ((int)threadIdx.x < L) {
+    t.Hl[threadIdx.x] = (int)shapes[2 * threadIdx.x];
+    t.Wl[threadIdx.x] = (int)shapes[2 * threadIdx.x + 1];
+    t.start[threadIdx.x] = (int)lsi[threadIdx.x];
+  }
+}
+
+// stage (x, y, w) of `nvalid` items starting at item0 into fields 0..2 of their records
 template <int kThr>
-__device__ __forceinline__ void stage_operands(const Prep& pr, const float* __restrict__ loc,
-                                               const float* __restrict__ attw,
-                                               const int64_t* __restrict__ shapes, float* s_loc, float* s_w,
-                                               int64_t item0, int nvalid, int H, int Nq, int L, int P) {
+__device__ __forceinline__ void stage_records(const Prep& pr, const float* __restrict__ loc,
+                                              const float* __restrict__ attw, const GLevels& lv, float* rec,
+                                              int64_t item0, int nvalid, int H, int Nq, int L, int P) {
   const int LP = L * P;
   if (pr.off_raw == nullptr) {
-    for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThr) s_loc[i] = loc[item0 * LP * 2 + i];
-    for (int i = threadIdx.x; i < nvalid * LP; i += kThr) s_w[i] = attw[item0 * LP + i];
+    for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
+      const int it = i / LP, lp = i - it * LP;
+      const float2 xy = reinterpret_cast<const float2*>(loc)[item0 * LP + i];
+      float* r = rec + rec_at(it, lp, LP);
+      r[0] = xy.x; r[1] = xy.y; r[2] = attw[item0 * LP + i];
+    }
     __syncthreads();
     return;
   }
@@ -154,12 +189,13 @@ __device__ __forceinline__ void stage_operands(const Prep& pr, const float* __re
     const int64_t item = item0 + it;
     const int64_t raw = raw_index(item, lp, H, Nq, LP, pr.Qn);
     const int l = lp / P, p = lp - l * P;
-    const int r = pr.mode == 0 ? l : p % pr.R;
+    const int rr = pr.mode == 0 ? l : p % pr.R;
     const float2 o = reinterpret_cast<const float2*>(pr.off_raw)[raw];
-    const float2 rf = reinterpret_cast<const float2*>(pr.ref)[(item / H) * pr.R + r];
-    s_loc[2 * i] = rf.x + o.x / (float)shapes[2 * l + 1];
-    s_loc[2 * i + 1] = rf.y + o.y / (float)shapes[2 * l];
-    s_w[i] = pr.logit_raw[raw];
+    const float2 rf = reinterpret_cast<const float2*>(pr.ref)[(item / H) * pr.R + rr];
+    float* r = rec + rec_at(it, lp, LP);
+    r[0] = rf.x + o.x / (float)lv.Wl[l];
+    r[1] = rf.y + o.y / (float)lv.Hl[l];
+    r[2] = pr.logit_raw[raw];
   }
   __syncthreads();
   // softmax over the LP logits of every item: 8 lanes per item, values in registers (LP <= 64)
@@ -171,7 +207,7 @@ __device__ __forceinline__ void stage_operands(const Prep& pr, const float* __re
 #pragma unroll
     for (int k = 0; k < kMaxLP / 8; ++k) {
       const int lp = sub + k * nlan;
-      e[k] = lp < LP ? s_w[it * LP + lp] : -INFINITY;
+      e[k] = lp < LP ? rec[rec_at(it, lp, LP) + 2] : -INFINITY;
       m = fmaxf(m, e[k]);
     }
 #pragma unroll
@@ -188,14 +224,92 @@ __device__ __forceinline__ void stage_operands(const Prep& pr, const float* __re
 #pragma unroll
     for (int k = 0; k < kMaxLP / 8; ++k) {
       const int lp = sub + k * nlan;
-      if (lp < LP) s_w[it * LP + lp] = e[k] / sum;
+      if (lp < LP) rec[rec_at(it, lp, LP) + 2] = e[k] / sum;
     }
   }
   __syncthreads();
   if (pr.loc_out != nullptr) {
-    for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThr) pr.loc_out[item0 * LP * 2 + i] = s_loc[i];
-    for (int i = threadIdx.x; i < nvalid * LP; i += kThr) pr.w_out[item0 * LP + i] = s_w[i];
+    for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
+      const int it = i / LP, lp = i - it * LP;
+      const float* r = rec + rec_at(it, lp, LP);
+      reinterpret_cast<float2*>(pr.loc_out)[item0 * LP + i] = make_float2(r[0], r[1]);
+      pr.w_out[item0 * LP + i] = r[2];
+    }
   }
+}
+
+// corner arithmetic of one sample, once: (x, y, w) in the record -> the forward or backward record
+template <int kThr, bool BWD>
+__device__ __forceinline__ void corner_records(const GLevels& lv, float* rec, int64_t item0, int nvalid, int Nv,
+                                               int H, int Nq, int L, int P) {
+  const int LP = L * P;
+  for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
+    const int it = i / LP, lp = i - it * LP;
+    const int l = lp / P;
+    const int64_t item = item0 + it;
+    const int h = (int)(item % H);
+    const int b = (int)(item / H / Nq);
+    const int Hl = lv.Hl[l], Wl = lv.Wl[l];
+    float* r = rec + rec_at(it, lp, LP);
+    const float x = pix(r[0], Wl), y = pix(r[1], Hl), w = r[2];
+    const bool in = y > -1.f && x > -1.f && y < Hl && x < Wl;
+    const int h0 = (int)floorf(y), w0 = (int)floorf(x);
+    const float lh = y - h0, lw = x - w0;
+    const bool t = h0 >= 0, bo = h0 + 1 <= Hl - 1, le = w0 >= 0, ri = w0 + 1 <= Wl - 1;
+    const int r0 = min(max(h0, 0), Hl - 1) * Wl, r1 = min(max(h0 + 1, 0), Hl - 1) * Wl;
+    const int c0 = min(max(w0, 0), Wl - 1), c1 = min(max(w0 + 1, 0), Wl - 1);
+    const unsigned line0 = ((unsigned)b * Nv + lv.start[l]) * H + h;          // line index of pixel 0 (128 B per line)
+    const unsigned o00 = (line0 + (unsigned)(r0 + c0) * H) * (kCh * 4), o01 = (line0 + (unsigned)(r0 + c1) * H) * (kCh * 4);
+    const unsigned o10 = (line0 + (unsigned)(r1 + c0) * H) * (kCh * 4), o11 = (line0 + (unsigned)(r1 + c1) * H) * (kCh * 4);
+    if (!BWD) {
+      const float hh = 1.f - lh, hw = 1.f - lw, a = in ? w : 0.f;
+      reinterpret_cast<float4*>(r)[0] = make_float4((t && le) ? hh * hw * a : 0.f, (t && ri) ? hh * lw * a : 0.f,
+                                                    (bo && le) ? lh * hw * a : 0.f, (bo && ri) ? lh * lw * a : 0.f);
+    } else {
+      const int meta = in ? ((int)(t && le) | ((int)(t && ri) << 1) | ((int)(bo && le) << 2) | ((int)(bo && ri) << 3) | (l << 4)) : -1;
+      reinterpret_cast<float4*>(r)[0] = make_float4(lh, lw, w, __int_as_float(meta));
+    }
+    reinterpret_cast<uint4*>(r)[1] = make_uint4(o00, o01, o10, o11);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float4 ldv(const float* __restrict__ value, unsigned byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(value) + byte_off);
+}
+
+__global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
+    float* __restrict__ out, int Nv, int H, int Nq, int L, int P, int64_t n_items, int nblocks, Prep pr) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ GLevels lv;
+  const int LP = L * P;
+  const int blk = xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;
+  load_levels(lv, shapes, lsi, L);
+  __syncthreads();
+  const int64_t item0 = (int64_t)blk * kItems;
+  const int nvalid = (int)min((int64_t)kItems, n_items - item0);
+  stage_records<kThreads>(pr, loc, attw, lv, smem, item0, nvalid, H, Nq, L, P);
+  corner_records<kThreads, false>(lv, smem, item0, nvalid, Nv, H, Nq, L, P);
+  const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
+  if (it >= nvalid) return;
+  const unsigned sub16 = sub * 16;
+  const float* r = smem + rec_at(it, 0, LP);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int lp = 0; lp < LP; ++lp, r += kRecF) {
+    const float4 w = reinterpret_cast<const float4*>(r)[0];
+    const uint4 o = reinterpret_cast<const uint4*>(r)[1];
+    const float4 v00 = ldv(value, o.x + sub16), v01 = ldv(value, o.y + sub16), v10 = ldv(value, o.z + sub16),
+                 v11 = ldv(value, o.w + sub16);
+    acc.x += w.x * v00.x + w.y * v01.x + w.z * v10.x + w.w * v11.x;
+    acc.y += w.x * v00.y + w.y * v01.y + w.z * v10.y + w.w * v11.y;
+    acc.z += w.x * v00.z + w.y * v01.z + w.z * v10.z + w.w * v11.z;
+    acc.w += w.x * v00.w + w.y * v01.w + w.z * v10.w + w.w * v11.w;
+  }
+  *reinterpret_cast<float4*>(out + (item0 + it) * kCh + sub * 4) = acc;
 }
 
 // store phase of the backward kernels: s_loc / s_w hold grad_loc / grad_w of `nvalid` items
@@ -225,52 +339,6 @@ __device__ __forceinline__ void store_grads(const Prep& pr, const float* __restr
     reinterpret_cast<float2*>(pr.g_off_raw)[raw] =
         make_float2(s_loc[2 * i] / (float)shapes[2 * l + 1], s_loc[2 * i + 1] / (float)shapes[2 * l]);
   }
-}
-
-__global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
-    const float* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
-    float* __restrict__ out, int Nv, int H, int Nq, int L, int P, int64_t n_items, int nblocks, Prep pr) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int LP = L * P;
-  float* s_loc = smem;                       // [kItems][LP*2]
-  float* s_w = smem + kItems * LP * 2;       // [kItems][LP]
-  const int blk = xcd_remap(blockIdx.x, nblocks);
-  if (blk >= nblocks) return;
-  const int64_t item0 = (int64_t)blk * kItems;
-  const int nvalid = (int)min((int64_t)kItems, n_items - item0);
-  stage_operands<kThreads>(pr, loc, attw, shapes, s_loc, s_w, item0, nvalid, H, Nq, L, P);   // coalesced
-  const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
-  if (it >= nvalid) return;
-  const int64_t item = item0 + it;
-  const int h = (int)(item % H);
-  const int64_t bq = item / H;
-  const int b = (int)(bq / Nq);
-  const int row_stride = H * kCh;
-  const float* vb = value + (int64_t)b * Nv * row_stride + h * kCh + sub * 4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float* ml = s_loc + it * LP * 2;
-  const float* mw = s_w + it * LP;
-  for (int l = 0; l < L; ++l) {
-    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-    const int base = (int)lsi[l] * row_stride;
-#pragma unroll 2
-    for (int p = 0; p < P; ++p) {
-      const float x = pix(ml[(l * P + p) * 2], Wl);
-      const float y = pix(ml[(l * P + p) * 2 + 1], Hl);
-      const float w = mw[l * P + p];
-      if (y > -1.f && x > -1.f && y < Hl && x < Wl) {
-        const Corner32 c = corners32(x, y, Hl, Wl, base, row_stride);
-        const float4 v00 = *reinterpret_cast<const float4*>(vb + c.o00), v01 = *reinterpret_cast<const float4*>(vb + c.o01),
-                     v10 = *reinterpret_cast<const float4*>(vb + c.o10), v11 = *reinterpret_cast<const float4*>(vb + c.o11);
-        acc.x += w * (c.w00 * v00.x + c.w01 * v01.x + c.w10 * v10.x + c.w11 * v11.x);
-        acc.y += w * (c.w00 * v00.y + c.w01 * v01.y + c.w10 * v10.y + c.w11 * v11.y);
-        acc.z += w * (c.w00 * v00.z + c.w01 * v01.z + c.w10 * v10.z + c.w11 * v11.z);
-        acc.w += w * (c.w00 * v00.w + c.w01 * v01.w + c.w10 * v10.w + c.w11 * v11.w);
-      }
-    }
-  }
-  *reinterpret_cast<float4*>(out + item * kCh + sub * 4) = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -506,16 +574,25 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
   build_tab(t, shapes, L);
   const int nbins = B * t.T * H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int carry_s = 0, carry_k = 0;                        // records / chunks before this slab of 1024 bins
-  for (int base = 0; base < nbins; base += kScanThreads) {
-    const int bin = base + threadIdx.x;
-    const int c = bin < nbins ? counts[bin] : 0;       // coalesced
-    const int k = (c + kChunk - 1) / kChunk;
-    int xs = c, xk = k;                                // inclusive wave scans
+  constexpr int kPer = 8;                              // consecutive bins per thread and slab
+  int carry_s = 0, carry_k = 0;                        // records / chunks before this slab of 8192 bins
+  int c[kPer], cn[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) { const int bin = threadIdx.x * kPer + j; c[j] = bin < nbins ? counts[bin] : 0; }
+  for (int base = 0; base < nbins; base += kScanThreads * kPer) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {                   // next slab's counts are in flight during this slab's scan
+      const int bin = base + kScanThreads * kPer + threadIdx.x * kPer + j;
+      cn[j] = bin < nbins ? counts[bin] : 0;
+    }
+    int ts = 0, tk = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) { ts += c[j]; tk += (c[j] + kChunk - 1) / kChunk; }
+    int xs = ts, xk = tk;                              // inclusive wave scans of the per-thread totals
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const int ts = __shfl_up(xs, d, 64), tk = __shfl_up(xk, d, 64);
-      if (lane >= d) { xs += ts; xk += tk; }
+      const int us = __shfl_up(xs, d, 64), uk = __shfl_up(xk, d, 64);
+      if (lane >= d) { xs += us; xk += uk; }
     }
     if (lane == 63) { s_wsum[wave] = xs; s_wchk[wave] = xk; }
     __syncthreads();
@@ -526,23 +603,29 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
       tot_s += a; tot_k += q;
       if (w < wave) { ws += a; wk += q; }
     }
-    if (bin < nbins) {
-      const int s = carry_s + ws + xs - c;
-      int kk = carry_k + wk + xk - k;
-      counts[bin] = s;
-      if (c) {
-        const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
-        int l = 0;
-        while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
-        const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
-        for (int i = 0; i < c; i += kChunk) {
-          desc[2 * kk] = make_int4(s + i, min(kChunk, c - i), l, b);
-          desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
-          ++kk;
+    int s = carry_s + ws + xs - ts, kk = carry_k + wk + xk - tk;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int bin = base + threadIdx.x * kPer + j;
+      if (bin < nbins) {
+        counts[bin] = s;
+        if (c[j]) {
+          const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
+          int l = 0;
+          while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
+          const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
+          for (int i = 0; i < c[j]; i += kChunk) {
+            desc[2 * kk] = make_int4(s + i, min(kChunk, c[j] - i), l, b);
+            desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
+            ++kk;
+          }
         }
+        s += c[j];
       }
     }
     carry_s += tot_s; carry_k += tot_k;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) c[j] = cn[j];
     __syncthreads();
   }
   if (threadIdx.x == 0) *n_chunks = carry_k;
@@ -669,72 +752,115 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
   }
 }
 
-// grad_sampling_loc / grad_attn_weight: a gather shaped like the forward (8 lanes x float4 per
-// (b,q,head) item, dot products reduced over the 8 lanes by xor shuffles), results leave through the
-// LDS staging area as coalesced stores.  No atomics.
+// grad_sampling_loc / grad_attn_weight: a gather shaped like the forward.  Per sample the 8 lanes of an item
+// fetch the four corner lines, dot them with the item's grad_out line and reduce the four dot products over the
+// 8 lanes with DPP adds (quad_perm x2 + row_half_mirror: 3 VALU operations per value; __shfl_xor would be a
+// ds_bpermute round trip per step); lane 0 parks them in the sample's record and ONE thread per sample turns
+// them into (grad_x, grad_y, grad_w) afterwards.  No atomics.
+__device__ __forceinline__ float reduce8(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return v;
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// N consecutive samples of one item: all 4N corner lines are requested before the first reduction
+template <int N>
+__device__ __forceinline__ void locw_samples(const float* __restrict__ value, float* r, const float4& go, int sub,
+                                             unsigned sub16) {
+  float4 v[N][4];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const uint4 o = reinterpret_cast<const uint4*>(r + k * kRecF)[1];
+    v[k][0] = ldv(value, o.x + sub16); v[k][1] = ldv(value, o.y + sub16);
+    v[k][2] = ldv(value, o.z + sub16); v[k][3] = ldv(value, o.w + sub16);
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const float d00 = reduce8(dot4(v[k][0], go)), d01 = reduce8(dot4(v[k][1], go));
+    const float d10 = reduce8(dot4(v[k][2], go)), d11 = reduce8(dot4(v[k][3], go));
+    if (sub == 0) reinterpret_cast<float4*>(r + k * kRecF)[1] = make_float4(d00, d01, d10, d11);
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv,
     int H, int Nq, int L, int P, int64_t n_items, int nblocks, Prep pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ GLevels lv;
+  __shared__ float s_dot[kItems];
   const int LP = L * P;
-  float* s_loc = smem;                       // [kItems][LP*2]  in: loc, out: grad_loc
-  float* s_w = smem + kItems * LP * 2;       // [kItems][LP]    in: w,   out: grad_w
-  float* s_dot = s_w + kItems * LP;          // [kItems]
   const int blk = xcd_remap(blockIdx.x, nblocks);
   if (blk >= nblocks) return;
+  load_levels(lv, shapes, lsi, L);
+  __syncthreads();
   const int64_t item0 = (int64_t)blk * kItems;
   const int nvalid = (int)min((int64_t)kItems, n_items - item0);
-  for (int i = threadIdx.x; i < nvalid * LP * 2; i += kThreads) s_loc[i] = loc[item0 * LP * 2 + i];
-  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) s_w[i] = attw[item0 * LP + i];
-  __syncthreads();
+  stage_records<kThreads>(Prep{}, loc, attw, lv, smem, item0, nvalid, H, Nq, L, P);     // saved (prepared) operands
+  corner_records<kThreads, true>(lv, smem, item0, nvalid, Nv, H, Nq, L, P);
   const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
   if (it < nvalid) {
-    const int64_t item = item0 + it;
-    const int h = (int)(item % H);
-    const int b = (int)(item / H / Nq);
-    const int row_stride = H * kCh;
-    const float* vb = value + (int64_t)b * Nv * row_stride + h * kCh + sub * 4;
-    const float4 go = *reinterpret_cast<const float4*>(grad_out + item * kCh + sub * 4);
-    float* ml = s_loc + it * LP * 2;
-    float* mw = s_w + it * LP;
-    for (int l = 0; l < L; ++l) {
-      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-      const int base = (int)lsi[l] * row_stride;
-      for (int p = 0; p < P; ++p) {
-        const float x = pix(ml[(l * P + p) * 2], Wl);
-        const float y = pix(ml[(l * P + p) * 2 + 1], Hl);
-        const float w = mw[l * P + p];
-        float gx = 0.f, gy = 0.f, gw = 0.f;
-        if (y > -1.f && x > -1.f && y < Hl && x < Wl) {     // uniform over the item's 8 lanes
-          const Corner32 c = corners32(x, y, Hl, Wl, base, row_stride);
-          const float4 v00 = *reinterpret_cast<const float4*>(vb + c.o00), v01 = *reinterpret_cast<const float4*>(vb + c.o01),
-                       v10 = *reinterpret_cast<const float4*>(vb + c.o10), v11 = *reinterpret_cast<const float4*>(vb + c.o11);
-          const float d00 = (v00.x * go.x + v00.y * go.y + v00.z * go.z + v00.w * go.w) * c.m00;
-          const float d01 = (v01.x * go.x + v01.y * go.y + v01.z * go.z + v01.w * go.w) * c.m01;
-          const float d10 = (v10.x * go.x + v10.y * go.y + v10.z * go.z + v10.w * go.w) * c.m10;
-          const float d11 = (v11.x * go.x + v11.y * go.y + v11.z * go.z + v11.w * go.w) * c.m11;
-          const float hh = 1.f - c.lh, hw = 1.f - c.lw;
-          gw = hh * hw * d00 + hh * c.lw * d01 + c.lh * hw * d10 + c.lh * c.lw * d11;
-          gx = w * Wl * (-hh * d00 + hh * d01 - c.lh * d10 + c.lh * d11);
-          gy = w * Hl * (-hw * d00 - c.lw * d01 + hw * d10 + c.lw * d11);
-        }
-#pragma unroll
-        for (int m = 1; m < kLanes; m <<= 1) {
-          gx += __shfl_xor(gx, m, 64); gy += __shfl_xor(gy, m, 64); gw += __shfl_xor(gw, m, 64);
-        }
-        // all 8 lanes of the item read (x, y, w) of this point before the shuffles finished
-        if (sub == 0) {
-          ml[(l * P + p) * 2] = gx;
-          ml[(l * P + p) * 2 + 1] = gy;
-          mw[l * P + p] = gw;
-        }
-      }
-    }
+    const unsigned sub16 = sub * 16;
+    const float4 go = *reinterpret_cast<const float4*>(grad_out + (item0 + it) * kCh + sub * 4);
+    float* r = smem + rec_at(it, 0, LP);
+    // (the DPP reductions are convergent operations, which keeps the compiler from unrolling a loop with a
+    //  run-time trip count: unrolled by hand, 16 lines in flight per wave)
+    int lp = 0;
+    for (; lp + 4 <= LP; lp += 4, r += 4 * kRecF) locw_samples<4>(value, r, go, sub, sub16);
+    for (; lp < LP; ++lp, r += kRecF) locw_samples<1>(value, r, go, sub, sub16);
   }
   __syncthreads();
-  store_grads<kThreads>(pr, attw, shapes, grad_loc, grad_w, s_loc, s_w, s_dot, item0, nvalid, H, Nq, L, P);
+  // one thread per sample: corner dot products -> gradients (fields 0..2 of the record; field 3 keeps w)
+  const bool fused = pr.g_off_raw != nullptr;
+  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) {
+    const int itx = i / LP, lp = i - itx * LP;
+    float* r = smem + rec_at(itx, lp, LP);
+    const float4 a = reinterpret_cast<const float4*>(r)[0];
+    const float4 d = reinterpret_cast<const float4*>(r)[1];
+    const int meta = __float_as_int(a.w);
+    float gx = 0.f, gy = 0.f, gw = 0.f;
+    if (meta >= 0) {
+      const int l = meta >> 4;
+      const float lh = a.x, lw = a.y, w = a.z, hh = 1.f - lh, hw = 1.f - lw;
+      const float d00 = (meta & 1) ? d.x : 0.f, d01 = (meta & 2) ? d.y : 0.f, d10 = (meta & 4) ? d.z : 0.f,
+                  d11 = (meta & 8) ? d.w : 0.f;
+      gw = hh * hw * d00 + hh * lw * d01 + lh * hw * d10 + lh * lw * d11;
+      gx = w * lv.Wl[l] * (-hh * d00 + hh * d01 - lh * d10 + lh * d11);
+      gy = w * lv.Hl[l] * (-hw * d00 - lw * d01 + hw * d10 + lw * d11);
+    }
+    if (!fused) {
+      reinterpret_cast<float2*>(grad_loc)[item0 * LP + i] = make_float2(gx, gy);
+      grad_w[item0 * LP + i] = gw;
+    } else {
+      reinterpret_cast<float4*>(r)[0] = make_float4(gx, gy, gw, a.z);
+    }
+  }
+  if (!fused) return;
+  __syncthreads();
+  // softmax backward: g_logit = w * (g_w - sum_j w_j g_w_j);  d loc / d off = 1 / (W_l, H_l)
+  for (int itx = threadIdx.x; itx < nvalid; itx += kThreads) {
+    float dot = 0.f;
+    for (int lp = 0; lp < LP; ++lp) {
+      const float* r = smem + rec_at(itx, lp, LP);
+      dot += r[3] * r[2];
+    }
+    s_dot[itx] = dot;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) {
+    const int itx = i / LP, lp = i - itx * LP;
+    const float4 a = reinterpret_cast<const float4*>(smem + rec_at(itx, lp, LP))[0];
+    const int64_t raw = raw_index(item0 + itx, lp, H, Nq, LP, pr.Qn);
+    const int l = lp / P;
+    pr.g_logit_raw[raw] = a.w * (a.z - s_dot[itx]);
+    reinterpret_cast<float2*>(pr.g_off_raw)[raw] = make_float2(a.x / (float)lv.Wl[l], a.y / (float)lv.Hl[l]);
+  }
 }
 
 // workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks: 4]
@@ -763,7 +889,8 @@ inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
 }
 
 inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
-  if ((int64_t)Nv * H * kCh >= (1ll << 31)) return true;       // 32-bit corner offsets inside a batch element
+  if ((int64_t)B * Nv * H * kCh * 4 >= (1ll << 32)) return true;   // 32-bit corner byte offsets into `value`
+  if (L > kGLv) return true;
   return B < 0 || Nv < 0 || H <= 0 || C != kCh || Nq < 0 || L <= 0 || P <= 0 || L * P > kMaxLP;
 }
 
@@ -780,7 +907,7 @@ static int msda_fwd_launch(const float* value, const int64_t* spatial_shapes,
   if (n_items == 0) return 0;
   const int nblocks = (int)((n_items + kItems - 1) / kItems);
   const int grid = ((nblocks + 7) / 8) * 8;
-  const size_t lds = sizeof(float) * kItems * L * P * 3;
+  const size_t lds = rec_lds_bytes(L * P);
   hipLaunchKernelGGL(msda_fwd_kernel, dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, Nv, H, Nq, L,
                      P, n_items, nblocks, pr);
@@ -828,7 +955,7 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
                        Nv, H, L, P, (int)(n_items * kCh * 4));
     const int nblocks = (int)((n_items + kItems - 1) / kItems);
     const int grid = ((nblocks + 7) / 8) * 8;
-    const size_t lds = sizeof(float) * (kItems * L * P * 3 + kItems);
+    const size_t lds = rec_lds_bytes(L * P);
     hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
                        grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
