@@ -54,9 +54,12 @@ def test_product_never_imports_oracle():
         src = f.read_text()
         assert "import oracle" not in src and "from oracle" not in src, f
         assert "from test_" not in src and "import test_" not in src, f
-    # bench.py: only the cpu_baseline leg
+    # bench.py: only the two functions of the cpu_baseline leg (run in a child process, outside the timed region)
     lines = (ROOT / "bench.py").read_text().splitlines()
     uses = [i for i, l in enumerate(lines) if "from oracle" in l or "import oracle" in l]
-    start = next(i for i, l in enumerate(lines) if l.startswith("def cpu_baseline("))
-    end = next(i for i, l in enumerate(lines) if i > start and l.startswith("def "))
-    assert uses and all(start < i < end for i in uses), uses
+
+    def span(name):
+        start = next(i for i, l in enumerate(lines) if l.startswith(f"def {name}("))
+        return start, next(i for i, l in enumerate(lines) if i > start and l.startswith("def "))
+    spans = [span("cpu_baseline"), span("cpu_baseline_ops")]
+    assert uses and all(any(a < i < b for a, b in spans) for i in uses), uses

@@ -42,3 +42,18 @@ def test_loader_batches_are_forward_train_kwargs(tmp_path):
             assert batch["img"].shape[:3] == (1, 3, 2) and len(batch["img_metas"]) == 1 and len(batch["gt_points"]) == 1
             seen.append(batch["img_metas"][0][2]["sample_idx"])
     assert len(seen) == 8 and len(set(seen)) == 7              # 7 usable samples, padded to 2 x 4
+
+
+def test_worker_seeds_differ_across_ranks_and_workers_and_collate_pads():
+    """worker k of every rank must not share a numpy stream (torch seeds the ranks identically): the reference's
+    num_workers * rank + worker_id + seed; samples whose augmentation drew different sizes are zero-padded."""
+    import torch
+    from vidar_amd.data.loader import collate, worker_seed
+    seeds = {worker_seed(4, r, w, 7) for r in range(8) for w in range(4)}
+    assert len(seeds) == 32 and worker_seed(4, 0, 0, 7) == 7 and worker_seed(4, 2, 3, 7) == 18
+    a = dict(img=torch.ones(5, 6, 3, 10, 12), img_metas={}, gt_points=torch.zeros(3, 5))
+    b = dict(img=torch.ones(5, 6, 3, 8, 16), img_metas={}, gt_points=torch.zeros(4, 5))
+    out = collate([a, None, b])
+    assert out["img"].shape == (2, 5, 6, 3, 10, 16)
+    assert float(out["img"][0, ..., :, 12:].abs().sum()) == 0 and float(out["img"][1, ..., 8:, :].abs().sum()) == 0
+    assert float(out["img"][0, ..., :10, :12].min()) == 1 and len(out["gt_points"]) == 2

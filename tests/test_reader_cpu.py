@@ -229,3 +229,53 @@ def test_getitem_retries_when_the_future_leaves_the_scene(tmp_path):
     assert ds._prepare(4) is None and ds._prepare(4, rand_interval=1) is not None
     s = ds[ds.usable_index.index(4)]
     assert s is not None and s["img_metas"][1]["sample_idx"] == "tok4"
+
+
+def test_voxel_point_sampler_shuffles_like_mmdet3d_before_sampling():
+    """CustomVoxelBasedPointSampler.__call__ ([3P] mmdet3d VoxelBasedPointSampler, restated): the points are
+    shuffled (twice when every point carries time 0: the empty previous-sweep set aliases the current array) before
+    the first point per voxel is kept -- so which point survives is random, key-frame points do not always win,
+    and the numpy stream advances exactly like two np.random.shuffle calls on the full array."""
+    from vidar_amd.data.reader import voxel_point_sampler, voxel_subsample
+    rng = np.random.default_rng(0)
+    pts = np.zeros((400, 5), np.float32)
+    pts[:, :3] = rng.uniform(-4, 4, (400, 3))
+    pts[:, 3] = np.arange(400)                           # identity of a point
+    np.random.seed(5)
+    got = voxel_point_sampler(pts.copy())
+    after = np.random.random()
+    np.random.seed(5)
+    ref = pts.copy()
+    np.random.shuffle(ref); np.random.shuffle(ref)
+    want = voxel_subsample(ref)
+    np.testing.assert_array_equal(got, want)
+    assert after == np.random.random(), "the numpy stream must advance by exactly two shuffles"
+    first = voxel_subsample(pts)                         # deterministic order: first point of each voxel
+    assert got.shape == first.shape and not np.array_equal(np.sort(got[:, 3]), np.sort(first[:, 3]))
+    # points of earlier sweeps (time != 0) are dropped when no prev_sweep_cfg is given, like the released configs
+    mixed = pts.copy(); mixed[200:, 4] = 0.05
+    np.random.seed(6)
+    out = voxel_point_sampler(mixed)
+    assert (out[:, 3] < 200).all()
+
+
+def test_named_recipes_carry_their_dataset_settings():
+    """tools/train.py --ann-file must train the recipe it names: temporal augmentation, subset stride, GT voxel
+    size and future length of the released configs (vidar_1_8_nusc_1future.py:14-24, :294; ..._3future.py:14-28,
+    :301; vidar_full_nusc_1future.py:14-24; OpenScene mini: :14-28, :292), and a released config file overrides."""
+    from vidar_amd.configs import dataset_kwargs, get_config
+    k = dataset_kwargs(get_config("vidar_1_8_nusc_1future"))
+    assert k["rand_frame_interval"] == (-1, 1) and k["load_frame_interval"] == 8 and k["voxel_size"] == (0.5,) * 3
+    assert k["future_length"] == 2 and k["queue_length"] == 4 and k["dataset"] == "nuscenes" and not k["test_mode"]
+    k = dataset_kwargs(get_config("vidar_1_8_nusc_3future"))
+    assert k["rand_frame_interval"] == (-1, 1, 2) and k["voxel_size"] == (1.0,) * 3 and k["future_length"] == 4
+    assert dataset_kwargs(get_config("vidar_1_8_nusc_3future"), test_mode=True)["future_length"] == 6
+    assert dataset_kwargs(get_config("vidar_full_nusc_1future"))["load_frame_interval"] == 1
+    k = dataset_kwargs(get_config("vidar_OpenScene_mini_full_3future"))
+    assert k["dataset"] == "nuplan" and k["rand_frame_interval"] == (1,) and abs(k["img_scale"] - 2 / 3) < 1e-12
+    ref = Path("/root/reference/projects/configs/vidar_pretrain/nusc_1_8_subset/vidar_1_8_nusc_3future.py")
+    if ref.exists():
+        from vidar_amd.plugin.config import Config
+        cfg = Config.fromfile(str(ref))
+        for name, test in (("vidar_1_8_nusc_3future", False), ("vidar_1_8_nusc_3future", True)):
+            assert dataset_kwargs(get_config(name), test, cfg) == dataset_kwargs(get_config(name), test)

@@ -76,10 +76,11 @@ def main(argv=None):
 
     n_samples = args.samples
     if args.ann_file:
+        from vidar_amd.configs import dataset_kwargs
         from vidar_amd.data import ViDARSequenceDataset
-        ds = ViDARSequenceDataset(args.ann_file, data_root=args.data_root, queue_length=meta["queue_length"],
-                                  future_length=n_future, test_mode=True,
-                                  dataset="nuplan" if "OpenScene" in meta["name"] else "nuscenes")
+        kw = dataset_kwargs(meta, test_mode=True)         # incl. the recipe's load_frame_interval (1/8 subsets)
+        kw["future_length"] = n_future
+        ds = ViDARSequenceDataset(args.ann_file, data_root=args.data_root, **kw)
         n_samples = len(ds) if args.samples <= 0 else min(args.samples, len(ds))
 
         def batch(i):                                                  # noqa: F811  (real data replaces the generator)

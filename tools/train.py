@@ -47,11 +47,12 @@ def main():
     rank, local, world = T.init_distributed()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(local)
+    file_cfg = None
     if args.config in VARIANTS:
         meta = get_config(args.config, with_backbone=not args.no_backbone)
         model_cfg, opt_cfg, clip = meta["model"], meta["optimizer"], meta["grad_clip"]
     else:
-        cfg = Config.fromfile(args.config)
+        cfg = file_cfg = Config.fromfile(args.config)
         cfg.merge_from_dict({k: ast.literal_eval(v) if v[:1] in "-0123456789[({TFN'\"" else v
                              for k, v in (o.split("=", 1) for o in args.cfg_options)})
         model_cfg = dict(cfg.model)
@@ -91,12 +92,14 @@ def main():
     if rank == 0:
         work.mkdir(parents=True, exist_ok=True)
     if args.ann_file:                      # real data: reader -> rank-sharded sampler -> collate -> device
+        from vidar_amd.configs import dataset_kwargs
         from vidar_amd.data import ViDARSequenceDataset
         from vidar_amd.data.loader import build_dataloader
-        ds = ViDARSequenceDataset(args.ann_file, data_root=args.data_root, queue_length=meta["queue_length"],
-                                  future_length=meta["future_frames"], augment=True,
-                                  dataset="nuplan" if "OpenScene" in meta["name"] else "nuscenes")
-        loader = build_dataloader(ds, 1, args.workers, world, rank, args.seed)
+        # the recipe's own temporal augmentation / subset stride / GT voxel size (not the reader's defaults)
+        ds = ViDARSequenceDataset(args.ann_file, data_root=args.data_root, augment=True,
+                                  **dataset_kwargs(meta, test_mode=False, file_cfg=file_cfg))
+        spg = file_cfg.data.samples_per_gpu if file_cfg is not None else meta["data"]["samples_per_gpu"]
+        loader = build_dataloader(ds, spg, args.workers, world, rank, args.seed)
 
         class _Epochs:                      # fit() re-iterates `batches` until --iters: one pass = one epoch
             epoch = 0

@@ -14,17 +14,25 @@ VARIANTS = {
     # name: future decoder frames/layers, LatentRendering step, head slices, cameras, GT future frames
     "vidar_1_8_nusc_1future": dict(future=0, dec_layers=1, lr_step=1.0, hist_pred=3, fut_pred=1,
                                    slice_w=(0.2, 0.4, 0.6, 1.0, 1.2), cams=6, future_frames=2,
-                                   backward_prev=1, drop_prev=(0.1, 3), img_hw=(928, 1600)),
+                                   backward_prev=1, drop_prev=(0.1, 3), img_hw=(928, 1600),
+                                   data=dict(rand_frame_interval=(-1, 1), load_frame_interval=8, voxel_size=0.5,
+                                             future_test=0)),
     "vidar_1_8_nusc_3future": dict(future=3, dec_layers=3, lr_step=0.5, hist_pred=3, fut_pred=1,
                                    slice_w=(0.2, 0.4, 0.6, 1.0, 1.2), cams=6, future_frames=4,
-                                   backward_prev=0, drop_prev=(0.0, None), img_hw=(928, 1600)),
+                                   backward_prev=0, drop_prev=(0.0, None), img_hw=(928, 1600),
+                                   data=dict(rand_frame_interval=(-1, 1, 2), load_frame_interval=8, voxel_size=1.0,
+                                             future_test=6)),
     "vidar_full_nusc_1future": dict(future=0, dec_layers=1, lr_step=0.5, hist_pred=3, fut_pred=1,
                                     slice_w=(0.2, 0.4, 0.6, 1.0, 1.2), cams=6, future_frames=1,
-                                    backward_prev=1, drop_prev=(0.1, 3), img_hw=(928, 1600)),
+                                    backward_prev=1, drop_prev=(0.1, 3), img_hw=(928, 1600),
+                                    data=dict(rand_frame_interval=(-1, 1, 2), load_frame_interval=1, voxel_size=0.5,
+                                              future_test=0)),
     "vidar_OpenScene_mini_full_3future": dict(future=3, dec_layers=3, lr_step=0.5, hist_pred=0,
                                               fut_pred=0, slice_w=(1.0,), cams=8, future_frames=3,
                                               backward_prev=0, drop_prev=(0.0, None),
-                                              img_hw=(736, 1280)),
+                                              img_hw=(736, 1280),
+                                              data=dict(rand_frame_interval=(1,), load_frame_interval=1,
+                                                        voxel_size=1.0, future_test=6, img_scale=2.0 / 3.0)),
 }
 
 
@@ -103,4 +111,34 @@ def get_config(name, bev_h=200, bev_w=200, with_backbone=False):
     shapes = [((h // s) + (1 if h % s else 0), (w // s) + (1 if w % s else 0)) for s in (8, 16, 32, 64)]
     return dict(name=name, model=model_config(name, bev_h, bev_w, with_backbone), queue_length=4,
                 future_frames=v["future_frames"], num_cams=v["cams"], img_hw=v["img_hw"],
-                fpn_shapes=shapes, optimizer=dict(lr=2e-4, weight_decay=0.01), grad_clip=35.0)
+                fpn_shapes=shapes, optimizer=dict(lr=2e-4, weight_decay=0.01), grad_clip=35.0,
+                data=dict(samples_per_gpu=1, workers_per_gpu=4, **v["data"]))
+
+
+def dataset_kwargs(meta, test_mode=False, file_cfg=None):
+    """-> keyword arguments of vidar_amd.data.ViDARSequenceDataset for a named recipe: the temporal augmentation
+    (`rand_frame_interval`), the 1/8 subset stride (`load_frame_interval`), the GT voxel size of the point sampler and
+    the future length of the split -- values of the released configs (vidar_1_8_nusc_1future.py:14-24, :294,
+    :338-342; vidar_1_8_nusc_3future.py:14-28, :301; vidar_full_nusc_1future.py:14-24; OpenScene/
+    vidar_OpenScene_mini_full_3future.py:14-28, :292).  `file_cfg`: a loaded released config file, whose own
+    `data.train` / `data.test` entries and point-sampler voxel size take precedence."""
+    d = dict(meta["data"])
+    kw = dict(queue_length=meta["queue_length"], future_length=d["future_test"] if test_mode else meta["future_frames"],
+              rand_frame_interval=tuple(d["rand_frame_interval"]), load_frame_interval=d["load_frame_interval"],
+              voxel_size=(d["voxel_size"],) * 3, test_mode=test_mode,
+              dataset="nuplan" if "OpenScene" in meta["name"] else "nuscenes")
+    if d.get("img_scale"):
+        kw["img_scale"] = d["img_scale"]
+    if file_cfg is not None:
+        split = file_cfg.data.test if test_mode else file_cfg.data.train
+        for key in ("queue_length", "future_length", "load_frame_interval"):
+            if key in split:
+                kw[key] = split[key]
+        if "rand_frame_interval" in split and not test_mode:
+            kw["rand_frame_interval"] = tuple(split["rand_frame_interval"])
+        for step in split.get("pipeline", []):
+            if step.get("type") == "CustomVoxelBasedPointSampler":
+                kw["voxel_size"] = tuple(step["cur_sweep_cfg"]["voxel_size"])
+    if test_mode:
+        kw["rand_frame_interval"] = (1,)
+    return kw

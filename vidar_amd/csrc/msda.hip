@@ -262,9 +262,10 @@ __device__ __forceinline__ void corner_records(const GLevels& lv, float* rec, in
     const unsigned o00 = (line0 + (unsigned)(r0 + c0) * H) * (kCh * 4), o01 = (line0 + (unsigned)(r0 + c1) * H) * (kCh * 4);
     const unsigned o10 = (line0 + (unsigned)(r1 + c0) * H) * (kCh * 4), o11 = (line0 + (unsigned)(r1 + c1) * H) * (kCh * 4);
     if (!BWD) {
-      const float hh = 1.f - lh, hw = 1.f - lw, a = in ? w : 0.f;
-      reinterpret_cast<float4*>(r)[0] = make_float4((t && le) ? hh * hw * a : 0.f, (t && ri) ? hh * lw * a : 0.f,
-                                                    (bo && le) ? lh * hw * a : 0.f, (bo && ri) ? lh * lw * a : 0.f);
+      // a sample outside the level (or with a NaN location) contributes nothing: selects, not products with 0
+      const float hh = 1.f - lh, hw = 1.f - lw;
+      reinterpret_cast<float4*>(r)[0] = make_float4((in && t && le) ? hh * hw * w : 0.f, (in && t && ri) ? hh * lw * w : 0.f,
+                                                    (in && bo && le) ? lh * hw * w : 0.f, (in && bo && ri) ? lh * lw * w : 0.f);
     } else {
       const int meta = in ? ((int)(t && le) | ((int)(t && ri) << 1) | ((int)(bo && le) << 2) | ((int)(bo && ri) << 3) | (l << 4)) : -1;
       reinterpret_cast<float4*>(r)[0] = make_float4(lh, lw, w, __int_as_float(meta));
@@ -443,27 +444,25 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
 // flushes the non-zero window lines with one atomic per line: ~2-3 M requests instead of 61 M.
 // grad_loc / grad_w come from a gather kernel shaped like the forward (no atomics at all).
 // ---------------------------------------------------------------------------------------------
-// Two accumulate kernels (VIDAR_MSDA_ACC): 1 = the destination window of a chunk lives in REGISTERS (tile edge 4:
-// 5x5 corner pixels = 25 accumulators per lane, indexed with the wave-uniform window offset through the VGPR
-// index mode) -- no LDS read-modify-write chain at all; 0 = round 2's private LDS window per wave (tile edge 8).
-#ifndef VIDAR_MSDA_ACC
-#define VIDAR_MSDA_ACC 1
-#endif
 #ifndef VIDAR_MSDA_TILE_SHIFT
-#define VIDAR_MSDA_TILE_SHIFT (VIDAR_MSDA_ACC ? 2 : 3)
+#define VIDAR_MSDA_TILE_SHIFT 3
 #endif
 constexpr int kTileShift = VIDAR_MSDA_TILE_SHIFT;
 constexpr int kTile = 1 << kTileShift;         // tile edge (top-left corner pixels)
 constexpr int kWin = kTile + 1;                // window edge (corner pixels)
-constexpr int kWinLines = kWin * kWin;         // window lines of 32 floats
-constexpr bool kRegWin = VIDAR_MSDA_ACC != 0;
-static_assert(!kRegWin || kWinLines <= 32, "the register window holds at most 32 lines");
+constexpr int kWinLines = kWin * kWin;         // 81 lines of 32 floats
+static_assert(kWinLines < 128, "the window line index shares a word with a 128-byte aligned offset");
 #ifndef VIDAR_MSDA_CHUNK
 #define VIDAR_MSDA_CHUNK 1024
 #endif
-constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor = per wave (tuning sweep: tools/tune_msda_tile.sh)
+constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor (tuning sweep: tools/tune_msda_tile.sh)
 constexpr int kMaxL = 16;                      // levels supported by the binned path
-constexpr int kTWaves = 4;                     // waves (= chunks) per workgroup of the accumulate kernel
+#ifndef VIDAR_MSDA_TWAVES
+#define VIDAR_MSDA_TWAVES 7
+#endif
+constexpr int kTWaves = VIDAR_MSDA_TWAVES;     // waves per workgroup of the accumulate kernel: 7 x (10.4 KB window + 1 KB) = 80 KB,
+                                               // two workgroups = 14 windows per CU (4 waves: 45.6 KB, three workgroups = 12)
+constexpr int kTileWgs = 4096 / kTWaves;       // persistent workgroups of the accumulate kernel (chunks are claimed dynamically)
 
 struct LevelTab {
   int Hl[kMaxL], Wl[kMaxL], ntx[kMaxL], toff[kMaxL];
@@ -631,117 +630,101 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
   if (threadIdx.x == 0) *n_chunks = carry_k;
 }
 
-// Accumulate kernel.  One chunk (<= kChunk records of one destination tile) per wave.
-// All 64 lanes of a wave work on ONE sample: lanes 0-31 own the 32 channels of the left corner column,
-// lanes 32-63 the right column; top row and bottom row are two accumulations.  Round 2 kept the window in LDS
-// (plain read-modify-writes, 10 KB per wave): a dependent ds_read -> fma -> ds_write chain per sample with 3-4
-// waves per SIMD, 0.62 ms for the 15 M samples of SpatialCrossAttention no matter how few VALU instructions
-// the per-sample scalar hand-off takes (18 -> 7 measured: 1.28 -> 1.23 ms), and ds_add_f32 on a shared window
-// is 8x slower still (10 ms: LDS float atomics retire at ~100 clocks per instruction).  So the window moved
-// into registers: with a 4x4 tile it is 5x5 lines = 25 accumulators per lane (lanes 32-63 hold the window
-// shifted by one column), addressed by the wave-uniform window offset through the VGPR index mode
-// (s_set_gpr_idx_on): v_mov out, v_fmac, v_mov in -- dependent VALU operations instead of LDS round trips.
-// Lane k of a 64-sample batch prepares sample k and parks its four corner weights in LDS as two 8-byte records
-// (left column, right column); in the sample loop every lane picks its column's (top, bottom) pair with one
-// ds_read_b64, the window offset and the grad_out line travel by v_readlane.
-typedef float f32x32 __attribute__((ext_vector_type(32)));
-
-__device__ __forceinline__ float go_line(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+// Accumulate kernel.  A wave claims one chunk (<= kChunk records of one destination tile) at a time from a
+// global counter (largest chunks first) and accumulates the tile's 9x9-pixel x 32-channel window in its PRIVATE
+// 10 KB LDS window with plain read-modify-writes.  All 64 lanes work on ONE sample and cover its four corner
+// lines with ONE 8-byte LDS operation: lane = (corner, channel pair) -- lanes 0-15 top-left, 16-31 top-right,
+// 32-47 bottom-left, 48-63 bottom-right -- so the 64 addresses of a step are always distinct (no atomics needed)
+// and a wave's LDS operations execute in order.  What was measured on the way here (profiles/r03_*):
+//   * round 2 handed the per-sample scalars to the lanes with ~18 VALU instructions (readlane + select chains);
+//     cutting that to 7 changed nothing (1.28 -> 1.23 ms): the kernel is bound by the LDS pipe (two 4-byte reads +
+//     two 4-byte writes per sample = 12 LDS cycles; SQ_WAIT_INST_LDS 101 M of 800 M wave cycles) and by the
+//     read -> fma -> write chain of the 12-15 windows that fit a CU;
+//   * ds_add_f32 on a window shared by the workgroup (no chain): 10 ms -- LDS float atomics retire at ~175 clocks
+//     per wave instruction;
+//   * the window in REGISTERS (4x4 tile, 25 accumulators per lane addressed through the VGPR index mode): the
+//     compiler's extract / fma / insert sequence costs 9 VALU + 10 SALU per sample, 0.53 ms -- no better.
+// Here a sample costs one ds_read_b32 (its corner weight: lane k of a 64-sample batch parks the four weights of
+// sample k in LDS), one ds_read_b64 + one ds_write_b64 (10 LDS cycles instead of 14), one v_readlane, one
+// v_pk_fma and a buffer load of its grad_out line (channel offset in a VGPR, line offset in an SGPR).
+__device__ __forceinline__ float2 go_pair(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
 }
 
-template <bool REG>
 __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
-    const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
+    const int* __restrict__ rec, const int4* __restrict__ desc, int* __restrict__ n_chunks, int Nv,
     int H, int L, int P, int go_bytes) {
-  __shared__ float s_win[REG ? 1 : kTWaves][REG ? 1 : kWinLines * kCh];
-  __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, bottom-left, top-right, bottom-right}
+  __shared__ __attribute__((aligned(16))) float s_win[kTWaves][kWinLines * kCh];
+  __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, top-right, bottom-left, bottom-right}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int chunk = blockIdx.x * kTWaves + wave;
-  if (chunk >= *n_chunks) return;                      // wave-uniform
-  const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
-  const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
-  const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-  float* win = s_win[REG ? 0 : wave];
-  f32x32 acc = 0.f;
-  if (!REG)
-    for (int i = lane; i < kWinLines * kCh; i += 64) win[i] = 0.f;
+  const int qd = lane >> 4, c2 = lane & 15;            // corner of this lane, its channel pair
+  float* win = s_win[wave];
+  float* wq = win + ((qd & 1) + (qd >> 1) * kWin) * kCh + 2 * c2;     // + (window line of the top-left corner) * kCh
+  const float* par = reinterpret_cast<const float*>(&s_par[wave][0]) + qd;
   const int LP = L * P;
-  const float2* par = reinterpret_cast<const float2*>(&s_par[wave][0]) + (lane >> 5);
-  float* wl = win + lane;
-  const int ch = lane & 31, ch4 = ch * 4;
-  // grad_out lines are fetched with buffer loads: per-lane byte offset (channel) in a VGPR, the sample's line offset
-  // in an SGPR -- no vector address arithmetic per sample
   const __amdgpu_buffer_rsrc_t go_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
-  for (int base = 0; base < n; base += 64) {
-    // lane k prepares sample base+k: window line of its top-left corner, the four corner weights
-    // (times the attention weight) and the offset of its grad_out line
-    const bool valid = base + lane < n;
-    const int s = rec[s0 + (valid ? base + lane : 0)];
-    const float2 xy = reinterpret_cast<const float2*>(loc)[s];
-    const float aw = valid ? attw[s] : 0.f;
-    const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
-    const int h0 = (int)floorf(y), w0 = (int)floorf(x);
-    const float lh = y - h0, lw = x - w0;
-    const float hh = (1.f - lh) * aw, lha = lh * aw;
-    __builtin_amdgcn_wave_barrier();                   // the previous batch's reads of s_par are done (in-order LDS)
-    s_par[wave][lane] = make_float4(hh * (1.f - lw), lha * (1.f - lw), hh * lw, lha * lw);
-    const int line = min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1);
-    // one word per sample for the v_readlane hand-off: byte offset of its grad_out line (a multiple of 128) | window line
-    const int pack = ((s / LP) * (kCh * 4)) | line;
-    __builtin_amdgcn_wave_barrier();
-    // groups of 8 samples, software-pipelined by hand: the weight pairs and grad_out lines of group k+1
-    // are requested before the accumulation of group k
-    float g[8], gn[8];
-    float2 a[8], an[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      g[u] = go_line(go_rsrc, ch4, __builtin_amdgcn_readlane(pack, u) & ~127);
-      a[u] = par[2 * u];                               // (top, bottom) weight of this lane's column
-    }
-#pragma unroll
-    for (int j0 = 0; j0 < 64; j0 += 8) {               // (samples past the end of the chunk carry zero weights)
-      if (j0 + 8 < 64) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          gn[u] = go_line(go_rsrc, ch4, __builtin_amdgcn_readlane(pack, (j0 + 8 + u) & 63) & ~127);
-          an[u] = par[2 * ((j0 + 8 + u) & 63)];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);               // keep the requests above ahead of the accumulation below
+  const int total = n_chunks[0];
+  for (;;) {
+    int claimed = 0;
+    if (lane == 0) claimed = atomicAdd(n_chunks + 1, 1);
+    const int chunk = total - 1 - __builtin_amdgcn_readfirstlane(claimed);    // the scan lists the coarse (long) levels last
+    if (chunk < 0) break;                                // wave-uniform
+    const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
+    const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    for (int i = lane; i < kWinLines * kCh / 4; i += 64) reinterpret_cast<float4*>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < n; base += 64) {
+      // lane k prepares sample base+k: window line of its top-left corner, the four corner weights
+      // (times the attention weight) and the offset of its grad_out line
+      const bool valid = base + lane < n;
+      const int s = rec[s0 + (valid ? base + lane : 0)];
+      const float2 xy = reinterpret_cast<const float2*>(loc)[s];
+      const float aw = valid ? attw[s] : 0.f;
+      const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
+      const int h0 = (int)floorf(y), w0 = (int)floorf(x);
+      const float lh = y - h0, lw = x - w0;
+      const float hh = (1.f - lh) * aw, lha = lh * aw;
+      __builtin_amdgcn_wave_barrier();                 // the previous batch's reads of s_par are done (in-order LDS)
+      s_par[wave][lane] = make_float4(hh * (1.f - lw), hh * lw, lha * (1.f - lw), lha * lw);
+      const int line = min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1);
+      // one word per sample for the v_readlane hand-off: byte offset of its grad_out line (a multiple of 128) | window line
+      const int pack = ((s / LP) * (kCh * 4)) | line;
+      __builtin_amdgcn_wave_barrier();
+      // groups of 8 samples, software-pipelined by hand: the weights and grad_out lines of group k+1 are
+      // requested before the window updates of group k (samples past the end of the chunk carry zero weights)
+      float2 g[8], gn[8];
+      float a[8], an[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int i = __builtin_amdgcn_readlane(pack, j0 + u) & 127;
-        if (REG) {
-          acc[i] += a[u].x * g[u];
-          acc[i + kWin] += a[u].y * g[u];
-        } else {
-          float* p = wl + i * kCh;
-          const float t0 = p[0], t1 = p[kWin * kCh];
-          p[0] = t0 + a[u].x * g[u];
-          p[kWin * kCh] = t1 + a[u].y * g[u];
-        }
+        g[u] = go_pair(go_rsrc, c2 * 8, __builtin_amdgcn_readlane(pack, u) & ~127);
+        a[u] = par[4 * u];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
-    }
-  }
-  // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
-  float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
-  if (REG) {
-    // register i of lanes 0-31 is window line i, of lanes 32-63 the line one column to the right
-    const int right = lane >> 5;
+      for (int j0 = 0; j0 < 64; j0 += 8) {
+        if (j0 + 8 < 64) {
 #pragma unroll
-    for (int i = 0; i < kWinLines; ++i) {
-      const int r = i / kWin, c = i % kWin + right;
-      const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
-      const float v = acc[i];
-      if (v != 0.f && py >= 0 && py < Hl && px >= 0 && px < Wl && c < kWin)
-        unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
+          for (int u = 0; u < 8; ++u) {
+            gn[u] = go_pair(go_rsrc, c2 * 8, __builtin_amdgcn_readlane(pack, (j0 + 8 + u) & 63) & ~127);
+            an[u] = par[4 * ((j0 + 8 + u) & 63)];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);             // keep the requests above ahead of the updates below
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float2* p = reinterpret_cast<float2*>(wq + (__builtin_amdgcn_readlane(pack, j0 + u) & 127) * kCh);
+          float2 t = *p;
+          t.x += a[u] * g[u].x; t.y += a[u] * g[u].y;
+          *p = t;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
+      }
     }
-  } else {
+    // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
+    const int ch = lane & 31;
+    float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
     for (int i = lane >> 5; i < kWinLines; i += 2) {
       const int r = i / kWin, c = i - r * kWin;
       const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
@@ -863,7 +846,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
   }
 }
 
-// workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks: 4]
+// workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks, claim counter: 4]
 // [chunk table: 4 * max_chunks][records: n_samples].  The level shapes live on the device, so the host
 // sizes the tables from a bound (bin_plan).
 struct BinPlan {
@@ -949,8 +932,8 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
                        n_chunks, B, H, L);
     hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
                        counts, rec, H, Nq, L, P);
-    const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
-    hipLaunchKernelGGL(msda_bwd_tile_kernel<kRegWin>, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
+    const int tgrid = (int)min((int64_t)kTileWgs, (p.max_chunks + kTWaves - 1) / kTWaves);
+    hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
                        Nv, H, L, P, (int)(n_items * kCh * 4));
     const int nblocks = (int)((n_items + kItems - 1) / kItems);

@@ -76,14 +76,38 @@ class DistributedSampler(Sampler):
 
 
 def collate(samples):
-    """list of dataset samples -> dict(img [bs,T,cams,3,H,W], img_metas [bs] of {t: meta}, gt_points [bs])"""
+    """list of dataset samples -> dict(img [bs,T,cams,3,H,W], img_metas [bs] of {t: meta}, gt_points [bs]).
+    Images of different sizes (CropResizeFlipImage draws a resize per sample) are zero-padded at the bottom /
+    right to the largest H and W of the batch, like mmcv's collate does for stacked DataContainers."""
     samples = [s for s in samples if s is not None]
-    return dict(img=torch.stack([s["img"] for s in samples]), img_metas=[s["img_metas"] for s in samples],
+    imgs = [s["img"] for s in samples]
+    H = max(i.shape[-2] for i in imgs); W = max(i.shape[-1] for i in imgs)
+    if any(i.shape[-2:] != (H, W) for i in imgs):
+        imgs = [torch.nn.functional.pad(i, (0, W - i.shape[-1], 0, H - i.shape[-2])) for i in imgs]
+    return dict(img=torch.stack(imgs), img_metas=[s["img_metas"] for s in samples],
                 gt_points=[s["gt_points"] for s in samples])
 
 
+def worker_seed(num_workers, rank, worker_id, seed):
+    """mmdet's worker_init_fn (apis of the reference's build_dataloader): num_workers * rank + worker_id + seed"""
+    return num_workers * rank + worker_id + seed
+
+
+def _seed_worker(worker_id, num_workers, rank, seed):
+    import random
+    s = worker_seed(num_workers, rank, worker_id, seed)
+    np.random.seed(s)
+    random.seed(s)
+    torch.manual_seed(s)
+
+
 def build_dataloader(dataset, samples_per_gpu=1, workers_per_gpu=4, num_replicas=1, rank=0, seed=0, test_mode=False):
+    """every worker of every rank gets its own numpy / random stream (photometric, flip, frame interval draws):
+    torch alone would hand worker k of EVERY rank the same seed, since the ranks seed torch identically"""
+    from functools import partial
     sampler = DistributedSampler(dataset, num_replicas, rank) if test_mode else \
         DistributedGroupSampler(dataset, samples_per_gpu, num_replicas, rank, seed)
+    init = partial(_seed_worker, num_workers=workers_per_gpu, rank=rank, seed=seed)
     return torch.utils.data.DataLoader(dataset, batch_size=samples_per_gpu, sampler=sampler, num_workers=workers_per_gpu,
-                                       collate_fn=collate, pin_memory=True, drop_last=False)
+                                       collate_fn=collate, pin_memory=True, drop_last=False,
+                                       worker_init_fn=init if workers_per_gpu > 0 else None)

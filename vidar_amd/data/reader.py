@@ -147,6 +147,26 @@ def voxel_subsample(points: np.ndarray, voxel_size=(1.0, 1.0, 1.0), point_cloud_
     return points[keep]
 
 
+def voxel_point_sampler(points: np.ndarray, voxel_size=(1.0, 1.0, 1.0), point_cloud_range=PC_RANGE,
+                        max_voxels: int = 50000, time_dim: int = 4) -> np.ndarray:
+    """`CustomVoxelBasedPointSampler.__call__` = mmdet3d v0.17.1 `VoxelBasedPointSampler.__call__` ([3P], restated
+    from memory, unpinned: mmdet3d is not vendored) around the reference's `_sample_points` (loading.py:226-241):
+    split into current-sweep points (time channel == 0) and previous-sweep points, SHUFFLE both with
+    `np.random.shuffle`, voxel-sample the current sweep (the released configs give no `prev_sweep_cfg`, so the
+    previous sweeps are dropped).  With `hard_sweeps_timestamp=0` every point carries time 0, the previous set is
+    empty and mmdet3d aliases it to the current array -- which is therefore shuffled twice, in place.  So the point
+    kept per voxel, the subset kept beyond `max_voxels` and the output order are random, and the numpy stream
+    advances by two shuffles per frame."""
+    cur_flag = points[:, time_dim] == 0
+    cur = points[cur_flag]
+    prev = points[~cur_flag]
+    if prev.shape[0] == 0:
+        prev = cur                                  # same array object, as in mmdet3d
+    np.random.shuffle(cur)
+    np.random.shuffle(prev)
+    return voxel_subsample(cur, voxel_size, point_cloud_range, max_voxels)
+
+
 def load_raw_images(paths: Sequence) -> list:
     """-> list of float32 [H, W, 3] arrays, channel order BGR like mmcv.imread (cv2), values 0..255
     (LoadMultiViewImageFromFiles(to_float32=True))"""
@@ -244,12 +264,12 @@ class ViDARSequenceDataset:
         if not self.test_mode and self.dataset == "nuscenes":        # train pipeline: sweeps + voxel subsample
             sweeps = [dict(s, data_path=self._path(s["data_path"])) for s in meta.get("sweeps", [])]
             pts = load_multi_sweeps(pts, sweeps, meta["timestamp"], self.sweeps_num, ego_mask=self.ego_mask)
-            pts = voxel_subsample(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
+            pts = voxel_point_sampler(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
         elif not self.test_mode:                                     # OpenScene: sweeps_num = 0, six columns
             pts = np.array(pts, dtype=np.float32, copy=True)         # LoadNuPlanPointsFromMultiSweeps with no sweeps:
             pts[:, 4] = 0                                            # key-frame time slot, then hard_sweeps_timestamp
             pts[:, -1] = 0                                           # on the LAST column (nuplan_loading.py:283-288)
-            pts = voxel_subsample(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
+            pts = voxel_point_sampler(pts, self.voxel_size, self.point_cloud_range, self.max_voxels)
         rec = dict(points=torch.from_numpy(np.ascontiguousarray(pts)), img_metas=meta)
         if with_images:
             imgs = load_raw_images([self._path(p) for p in meta["img_filename"]])

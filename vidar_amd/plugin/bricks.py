@@ -132,7 +132,6 @@ def rotate_nearest(img, angle_deg, center):
 # --------------------------------------------------------------------------------------------------
 # LayerNorm(dropout(x) + residual) as one HIP pass each way (csrc/norm_fuse.hip)
 # --------------------------------------------------------------------------------------------------
-_DROP_CALLS = [0]
 
 
 def can_fuse_norm(norm, x):
@@ -176,11 +175,13 @@ class _DropAddLayerNorm(torch.autograd.Function):
 
 def drop_add_layernorm(x, residual, norm, p, training):
     """norm(dropout(x, p) + residual).  CUDA fp32 [.., 256] tensors with an affine nn.LayerNorm take the fused HIP
-    kernels (dropout mask = hash of (seed, element), seed drawn from torch's seeded state once per call, so a
-    manual_seed run is reproducible); everything else is the three torch ops."""
+    kernels (dropout mask = hash of (seed, element), seed drawn from torch's CPU generator once per call, so a
+    manual_seed run is reproducible and a recomputed forward under torch.utils.checkpoint sees the same mask);
+    everything else is the three torch ops."""
     p = float(p) if training else 0.0
     if can_fuse_norm(norm, x) and residual.shape == x.shape and residual.dtype == x.dtype:
-        _DROP_CALLS[0] += 1
-        seed = (torch.initial_seed() * 0x9E3779B1 + _DROP_CALLS[0] * 0x85EBCA77) & 0xFFFFFFFF
+        # the 32-bit mask seed is DRAWN from torch's CPU generator (no device sync): checkpoint's RNG preservation,
+        # get_rng_state / set_rng_state and manual_seed all cover it, and two models in one process do not share it
+        seed = int(torch.randint(0, 1 << 31, (1,), dtype=torch.int64).item()) * 2 + 1 if p > 0.0 else 0
         return _DropAddLayerNorm.apply(x, residual, norm.weight, norm.bias, p, float(norm.eps), seed)
     return norm(F.dropout(x, p, training) + residual)

@@ -188,7 +188,10 @@ class CustomMSDeformableAttention(PredictionMSDeformableAttention):
                          init_cfg=init_cfg)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
-                reference_points=None, spatial_shapes=None, level_start_index=None, flag="decoder", **kwargs):
+                reference_points=None, spatial_shapes=None, level_start_index=None, flag="decoder", fuse_norm=None,
+                **kwargs):
+        # `fuse_norm` (the layer's offer to fuse the following LayerNorm) must not reach the parent here: it would
+        # normalise BEFORE the identity is added below.  The norm is applied after the add instead.
         if value is None:
             value = query
         if identity is None:
@@ -210,4 +213,5 @@ class CustomMSDeformableAttention(PredictionMSDeformableAttention):
         # the parent returned dropout(output_proj(attn)) + 0: add the identity in the caller's layout
         if not self.batch_first:
             out = out.permute(1, 0, 2)
-        return out + identity
+        out = out + identity
+        return fuse_norm(out) if fuse_norm is not None else out

@@ -28,10 +28,22 @@ def _ok(*ts):
             raise RuntimeError("ms_deform_attn: tensors must be contiguous")
 
 
+def _dtypes(floats, ints):
+    """raw pointers cross the C ABI: anything but float32 operands / int64 shape tables would be reinterpreted
+    silently (the reference's MultiScaleDeformableAttnFunction_fp16 casts to float32 before calling the op)"""
+    for t in floats:
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"ms_deform_attn: float32 tensors required, got {t.dtype}")
+    for t in ints:
+        if t.dtype != torch.int64:
+            raise RuntimeError(f"ms_deform_attn: int64 spatial_shapes / level_start_index required, got {t.dtype}")
+
+
 def ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
                            attention_weights, im2col_step=64):
     """-> output [bs, num_queries, num_heads * channels]; `im2col_step` accepted, meaningless here."""
     _ok(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights)
+    _dtypes((value, sampling_locations, attention_weights), (value_spatial_shapes, value_level_start_index))
     B, Nv, H, C, Nq, L, P = _dims(value, sampling_locations)
     out = torch.empty((B, Nq, H * C), dtype=torch.float32, device=value.device)
     check(lib().vidar_msda_fwd_f32(ptr(value), ptr(value_spatial_shapes), ptr(value_level_start_index),
@@ -47,6 +59,8 @@ def ms_deform_attn_backward(value, value_spatial_shapes, value_level_start_index
     function.py:146-148; this op overwrites them, which is the same result).  Returns None like mmcv."""
     _ok(value, value_spatial_shapes, value_level_start_index, sampling_locations, attention_weights,
         grad_output, grad_value, grad_sampling_loc, grad_attn_weight)
+    _dtypes((value, sampling_locations, attention_weights, grad_output, grad_value, grad_sampling_loc,
+             grad_attn_weight), (value_spatial_shapes, value_level_start_index))
     B, Nv, H, C, Nq, L, P = _dims(value, sampling_locations)
     from ..plugin.modules.multi_scale_deformable_attn_function import _bwd_workspace
     ws, nbytes = _bwd_workspace(value, B, Nv, H, Nq, L, P, None)
