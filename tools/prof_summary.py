@@ -6,6 +6,26 @@ import sqlite3
 import sys
 
 
+OWN = ("msda_", "dcn_", "affine_act", "lr_", "ray_", "knn", "sca_", "drop_add_ln", "dvr", "dvxlr", "vidar_",
+       "rows_", "bev_", "latent_")
+
+
+def category(name):
+    """library GEMMs (Tensile kernels of hipBLASLt / rocBLAS) / MIOpen convolutions / this library's HIP kernels /
+    torch eager kernels / the rest (fills, copies, RCCL)"""
+    short = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if short.startswith("Cijk_") or "Cijk_" in short[:40]:
+        return "library GEMM (hipBLASLt / rocBLAS)"
+    if short.startswith(("miopen", "igemm_", "batched_transpose", "naive_conv", "gridwise_", "SubTensorOp", "MIOpen")) \
+            or "ck::" in short[:60] or "Conv" in short[:40]:
+        return "MIOpen convolution"
+    if short.startswith("at::") or "at::native" in short[:80] or short.startswith(("c10::", "torch::")):
+        return "torch eager"
+    if any(short.startswith(p) for p in OWN):
+        return "vidar_amd HIP kernels"
+    return "other (fills, copies, collectives)"
+
+
 def main(argv):
     path = argv[0]
     steps, csv_out, subs = 0, False, []
@@ -33,6 +53,11 @@ def main(argv):
                           f"from {kd} d join {sym} s on d.kernel_id=s.id {where} group by s.display_name order by 4 desc"))
     total = sum(r[3] for r in rows)
     ncalls = sum(r[1] for r in rows)
+    cats = {}
+    for name, n, avg, tot, mn in rows:
+        k = category(name)
+        c0 = cats.setdefault(k, [0, 0.0])
+        c0[0] += n; c0[1] += tot
     if csv_out:
         print("Name,Calls,TotalMs,AverageUs,MinUs,Percentage")
     else:
@@ -46,7 +71,11 @@ def main(argv):
         else:
             print(f"{short:70s} {n / div:8.1f} {avg / 1e3:10.1f} {mn / 1e3:10.1f} {tot / 1e6 / div:10.2f} {100.0 * tot / total:6.2f}")
     unit = " per step" if steps else ""
-    print(f"# {ncalls / div:.0f} launches{unit}, {total / 1e6 / div:.2f} ms kernel time{unit}", file=sys.stderr)
+    tail = [f"# {ncalls / div:.0f} launches{unit}, {total / 1e6 / div:.2f} ms kernel time{unit}"]
+    for k, (n, tot) in sorted(cats.items(), key=lambda kv: -kv[1][1]):
+        tail.append(f"#   {k:34s} {n / div:8.1f} launches {tot / 1e6 / div:9.2f} ms{unit}")
+    print("\n".join(tail))
+    print("\n".join(tail), file=sys.stderr)
 
 
 if __name__ == "__main__":

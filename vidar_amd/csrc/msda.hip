@@ -666,12 +666,14 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
   const int LP = L * P;
   const __amdgpu_buffer_rsrc_t go_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
   const int total = n_chunks[0];
+  // chunks are claimed one AHEAD: the counter's round trip (and nothing else) overlaps the previous chunk's work
+  int claimed = 0;
+  if (lane == 0) claimed = atomicAdd(n_chunks + 1, 1);
   for (;;) {
-    int claimed = 0;
-    if (lane == 0) claimed = atomicAdd(n_chunks + 1, 1);
     const int chunk = total - 1 - __builtin_amdgcn_readfirstlane(claimed);    // the scan lists the coarse (long) levels last
     if (chunk < 0) break;                                // wave-uniform
     const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
+    if (lane == 0) claimed = atomicAdd(n_chunks + 1, 1);
     const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
     const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
     for (int i = lane; i < kWinLines * kCh / 4; i += 64) reinterpret_cast<float4*>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
