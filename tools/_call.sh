@@ -1,6 +1,5 @@
 mkdir -p gpurun_out
-(timeout 900 python -m pytest tests/test_msda_gpu.py tests/test_norm_fuse_gpu.py -x -q 2>&1 | tail -4) > gpurun_out/r03_e_tests.log
-(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o run -- python $GRAFT_REPO_ROOT/tools/kbench.py msda > $GRAFT_REPO_ROOT/gpurun_out/r03_e_kbench_msda.log 2>&1; f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); grep -v "at::native" "$f" > $GRAFT_REPO_ROOT/gpurun_out/r03_kbench_msda_kernel_stats_e.csv)
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/st && timeout 900 rocprofv3 --kernel-trace -d /tmp/st -o run -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 10 --warmup 5 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" > $GRAFT_REPO_ROOT/gpurun_out/r03_e_bench_traced.json 2> /tmp/st.err; db=$(find /tmp/st -name "*.db" | head -1); python $GRAFT_REPO_ROOT/tools/prof_summary.py "$db" --steps 10 > $GRAFT_REPO_ROOT/gpurun_out/r03_step_kernel_summary_timed_region.txt 2> /dev/null; tail -3 /tmp/st.err)
-(timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --op-table > gpurun_out/r03_e_bench_driver_like.json 2> gpurun_out/r03_e_optable.txt)
-cat gpurun_out/r03_e_tests.log; grep binned=True gpurun_out/r03_e_kbench_msda.log | cut -c1-110; tail -8 gpurun_out/r03_step_kernel_summary_timed_region.txt; cut -c1-400 gpurun_out/r03_e_bench_driver_like.json; grep -v Warn gpurun_out/r03_e_optable.txt | head -24
+tools/tune_msda_tile.sh > gpurun_out/r03_msda_tile_sweep4.log 2>&1
+(timeout 300 python -m pytest tests/test_msda_gpu.py -x -q 2>&1 | tail -3) > gpurun_out/r03_f_tests.log
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o run -- python $GRAFT_REPO_ROOT/tools/kbench.py msda > $GRAFT_REPO_ROOT/gpurun_out/r03_f_kbench_msda.log 2>&1; f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); grep -v "at::native" "$f" > $GRAFT_REPO_ROOT/gpurun_out/r03_kbench_msda_kernel_stats_f.csv)
+cat gpurun_out/r03_msda_tile_sweep4.log gpurun_out/r03_f_tests.log

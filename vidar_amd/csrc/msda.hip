@@ -457,12 +457,7 @@ static_assert(kWinLines < 128, "the window line index shares a word with a 128-b
 #endif
 constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor (tuning sweep: tools/tune_msda_tile.sh)
 constexpr int kMaxL = 16;                      // levels supported by the binned path
-#ifndef VIDAR_MSDA_TWAVES
-#define VIDAR_MSDA_TWAVES 7
-#endif
-constexpr int kTWaves = VIDAR_MSDA_TWAVES;     // waves per workgroup of the accumulate kernel: 7 x (10.4 KB window + 1 KB) = 80 KB,
-                                               // two workgroups = 14 windows per CU (4 waves: 45.6 KB, three workgroups = 12)
-constexpr int kTileWgs = 4096 / kTWaves;       // persistent workgroups of the accumulate kernel (chunks are claimed dynamically)
+constexpr int kTWaves = 4;                     // waves (= chunks, private 10 KB windows) per workgroup of the accumulate kernel
 
 struct LevelTab {
   int Hl[kMaxL], Wl[kMaxL], ntx[kMaxL], toff[kMaxL];
@@ -603,23 +598,29 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
       if (w < wave) { ws += a; wk += q; }
     }
     int s = carry_s + ws + xs - ts, kk = carry_k + wk + xk - tk;
+    // (head, tile, level, batch element) of this thread's first bin by division ONCE, then counted up: the whole scan
+    // runs on one CU, three integer divisions per bin were most of its time
+    int bin = base + threadIdx.x * kPer;
+    int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
+    int l = 0;
+    while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
+    int ty = (tl - t.toff[l]) / t.ntx[l], tx = (tl - t.toff[l]) - ty * t.ntx[l];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-      const int bin = base + threadIdx.x * kPer + j;
+    for (int j = 0; j < kPer; ++j, ++bin) {
       if (bin < nbins) {
         counts[bin] = s;
-        if (c[j]) {
-          const int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
-          int l = 0;
-          while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
-          const int tile = tl - t.toff[l], ty = tile / t.ntx[l], tx = tile - ty * t.ntx[l];
-          for (int i = 0; i < c[j]; i += kChunk) {
-            desc[2 * kk] = make_int4(s + i, min(kChunk, c[j] - i), l, b);
-            desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
-            ++kk;
-          }
+        for (int i = 0; i < c[j]; i += kChunk) {
+          desc[2 * kk] = make_int4(s + i, min(kChunk, c[j] - i), l, b);
+          desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
+          ++kk;
         }
         s += c[j];
+      }
+      if (++h == H) {                                    // next tile
+        h = 0; ++tl;
+        if (++tx == t.ntx[l]) { tx = 0; ++ty; }
+        if (tl == t.T) { tl = 0; ++b; l = 0; tx = ty = 0; }
+        else if (l + 1 < L && tl == t.toff[l + 1]) { ++l; tx = ty = 0; }
       }
     }
     carry_s += tot_s; carry_k += tot_k;
@@ -630,110 +631,108 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
   if (threadIdx.x == 0) *n_chunks = carry_k;
 }
 
-// Accumulate kernel.  A wave claims one chunk (<= kChunk records of one destination tile) at a time from a
-// global counter (largest chunks first) and accumulates the tile's 9x9-pixel x 32-channel window in its PRIVATE
-// 10 KB LDS window with plain read-modify-writes.  All 64 lanes work on ONE sample and cover its four corner
-// lines with ONE 8-byte LDS operation: lane = (corner, channel pair) -- lanes 0-15 top-left, 16-31 top-right,
-// 32-47 bottom-left, 48-63 bottom-right -- so the 64 addresses of a step are always distinct (no atomics needed)
-// and a wave's LDS operations execute in order.  What was measured on the way here (profiles/r03_*):
+// Accumulate kernel.  One chunk (<= kChunk records of one destination tile) per wave: the wave accumulates the tile's
+// 9x9-pixel x 32-channel window in its PRIVATE 10 KB LDS window with plain read-modify-writes.  All 64 lanes work on
+// ONE sample -- lanes 0-31 own the 32 channels of the left corner column, lanes 32-63 the right column, top row
+// and bottom row are two LDS updates -- so the 64 addresses of a step are always distinct (no atomics needed) and a
+// wave's LDS operations execute in order.  What round 3 measured on the way here (profiles/r03_msda_tile_sweep_*,
+// profiles/r03_pmc_msda_sca_*; SCA shape, whole backward):
 //   * round 2 handed the per-sample scalars to the lanes with ~18 VALU instructions (readlane + select chains);
-//     cutting that to 7 changed nothing (1.28 -> 1.23 ms): the kernel is bound by the LDS pipe (two 4-byte reads +
-//     two 4-byte writes per sample = 12 LDS cycles; SQ_WAIT_INST_LDS 101 M of 800 M wave cycles) and by the
-//     read -> fma -> write chain of the 12-15 windows that fit a CU;
-//   * ds_add_f32 on a window shared by the workgroup (no chain): 10 ms -- LDS float atomics retire at ~175 clocks
-//     per wave instruction;
+//     cutting that to ~6 (below) bought 1.28 -> 1.18 ms together with the cheaper scan: the kernel is not VALU bound
+//     but LDS bound -- two 4-byte reads + two 4-byte writes per sample = 12 LDS cycles, SQ_WAIT_INST_LDS 101 M of
+//     800 M wave cycles -- and bound by the read -> fma -> write chain of the 12 windows that fit a CU;
+//   * ds_add_f32 on a window shared by the workgroup (no chain): 10 ms -- LDS float atomics retire at ~175 clocks per
+//     wave instruction;
 //   * the window in REGISTERS (4x4 tile, 25 accumulators per lane addressed through the VGPR index mode): the
-//     compiler's extract / fma / insert sequence costs 9 VALU + 10 SALU per sample, 0.53 ms -- no better.
-// Here a sample costs one ds_read_b32 (its corner weight: lane k of a 64-sample batch parks the four weights of
-// sample k in LDS), one ds_read_b64 + one ds_write_b64 (10 LDS cycles instead of 14), one v_readlane, one
-// v_pk_fma and a buffer load of its grad_out line (channel offset in a VGPR, line offset in an SGPR).
-__device__ __forceinline__ float2 go_pair(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-  return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+//     compiler's extract / fma / insert sequence costs 9 VALU + 10 SALU per sample: 1.36 ms;
+//   * one 8-byte read-modify-write covering the four corners (lane = corner x channel pair): 1.18 ms vs 1.15 ms;
+//   * a resident grid striding over the chunk table (1.33 ms) or claiming chunks from a counter (1.30 ms) instead of
+//     one wave per descriptor slot of the host's bound (1.15 ms): the hardware dispatcher balances the very unequal
+//     chunks better than either, and waves that find no chunk cost almost nothing.
+// Lane k of a 64-sample batch prepares sample k and parks its four corner weights in LDS as two 8-byte records (left
+// column, right column); in the sample loop every lane picks its column's (top, bottom) pair with ONE ds_read_b64
+// whose address does not depend on the sample, the window line and the grad_out line travel in one v_readlane, and
+// the grad_out line is a buffer load (channel offset in a VGPR, line offset in an SGPR: no vector address arithmetic).
+__device__ __forceinline__ float go_one(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
 }
 
 __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
-    const int* __restrict__ rec, const int4* __restrict__ desc, int* __restrict__ n_chunks, int Nv,
+    const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
     int H, int L, int P, int go_bytes) {
   __shared__ __attribute__((aligned(16))) float s_win[kTWaves][kWinLines * kCh];
-  __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, top-right, bottom-left, bottom-right}
+  __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, bottom-left, top-right, bottom-right}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int qd = lane >> 4, c2 = lane & 15;            // corner of this lane, its channel pair
+  const int chunk = blockIdx.x * kTWaves + wave;
+  if (chunk >= *n_chunks) return;                      // wave-uniform
+  const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
+  const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
+  const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
   float* win = s_win[wave];
-  float* wq = win + ((qd & 1) + (qd >> 1) * kWin) * kCh + 2 * c2;     // + (window line of the top-left corner) * kCh
-  const float* par = reinterpret_cast<const float*>(&s_par[wave][0]) + qd;
+  const int half = lane >> 5, ch = lane & 31;
+  float* wq = win + half * kCh + ch;                   // + (window line of the top-left corner) * kCh
+  const float2* par = reinterpret_cast<const float2*>(&s_par[wave][0]) + half;
   const int LP = L * P;
   const __amdgpu_buffer_rsrc_t go_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
-  const int total = n_chunks[0];
-  // chunks are claimed one AHEAD: the counter's round trip (and nothing else) overlaps the previous chunk's work
-  int claimed = 0;
-  if (lane == 0) claimed = atomicAdd(n_chunks + 1, 1);
-  for (;;) {
-    const int chunk = total - 1 - __builtin_amdgcn_readfirstlane(claimed);    // the scan lists the coarse (long) levels last
-    if (chunk < 0) break;                                // wave-uniform
-    const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
-    if (lane == 0) claimed = atomicAdd(n_chunks + 1, 1);
-    const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
-    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-    for (int i = lane; i < kWinLines * kCh / 4; i += 64) reinterpret_cast<float4*>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0; base < n; base += 64) {
-      // lane k prepares sample base+k: window line of its top-left corner, the four corner weights
-      // (times the attention weight) and the offset of its grad_out line
-      const bool valid = base + lane < n;
-      const int s = rec[s0 + (valid ? base + lane : 0)];
-      const float2 xy = reinterpret_cast<const float2*>(loc)[s];
-      const float aw = valid ? attw[s] : 0.f;
-      const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
-      const int h0 = (int)floorf(y), w0 = (int)floorf(x);
-      const float lh = y - h0, lw = x - w0;
-      const float hh = (1.f - lh) * aw, lha = lh * aw;
-      __builtin_amdgcn_wave_barrier();                 // the previous batch's reads of s_par are done (in-order LDS)
-      s_par[wave][lane] = make_float4(hh * (1.f - lw), hh * lw, lha * (1.f - lw), lha * lw);
-      const int line = min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1);
-      // one word per sample for the v_readlane hand-off: byte offset of its grad_out line (a multiple of 128) | window line
-      const int pack = ((s / LP) * (kCh * 4)) | line;
-      __builtin_amdgcn_wave_barrier();
-      // groups of 8 samples, software-pipelined by hand: the weights and grad_out lines of group k+1 are
-      // requested before the window updates of group k (samples past the end of the chunk carry zero weights)
-      float2 g[8], gn[8];
-      float a[8], an[8];
+  for (int i = lane; i < kWinLines * kCh / 4; i += 64) reinterpret_cast<float4*>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = 0; base < n; base += 64) {
+    // lane k prepares sample base+k: window line of its top-left corner, the four corner weights
+    // (times the attention weight) and the offset of its grad_out line
+    const bool valid = base + lane < n;
+    const int s = rec[s0 + (valid ? base + lane : 0)];
+    const float2 xy = reinterpret_cast<const float2*>(loc)[s];
+    const float aw = valid ? attw[s] : 0.f;
+    const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
+    const int h0 = (int)floorf(y), w0 = (int)floorf(x);
+    const float lh = y - h0, lw = x - w0;
+    const float hh = (1.f - lh) * aw, lha = lh * aw;
+    __builtin_amdgcn_wave_barrier();                   // the previous batch's reads of s_par are done (in-order LDS)
+    s_par[wave][lane] = make_float4(hh * (1.f - lw), lha * (1.f - lw), hh * lw, lha * lw);
+    const int line = min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1);
+    // one word per sample for the v_readlane hand-off: byte offset of its grad_out line (a multiple of 128) | window line
+    const int pack = ((s / LP) * (kCh * 4)) | line;
+    __builtin_amdgcn_wave_barrier();
+    // groups of 8 samples, software-pipelined by hand: the weight pairs and grad_out lines of group k+1 are
+    // requested before the window updates of group k (samples past the end of the chunk carry zero weights)
+    float g[8], gn[8];
+    float2 a[8], an[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        g[u] = go_pair(go_rsrc, c2 * 8, __builtin_amdgcn_readlane(pack, u) & ~127);
-        a[u] = par[4 * u];
-      }
+    for (int u = 0; u < 8; ++u) {
+      g[u] = go_one(go_rsrc, ch * 4, __builtin_amdgcn_readlane(pack, u) & ~127);
+      a[u] = par[2 * u];                               // (top, bottom) weight of this lane's column
+    }
 #pragma unroll
-      for (int j0 = 0; j0 < 64; j0 += 8) {
-        if (j0 + 8 < 64) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            gn[u] = go_pair(go_rsrc, c2 * 8, __builtin_amdgcn_readlane(pack, (j0 + 8 + u) & 63) & ~127);
-            an[u] = par[4 * ((j0 + 8 + u) & 63)];
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);             // keep the requests above ahead of the updates below
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      if (j0 + 8 < 64) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          float2* p = reinterpret_cast<float2*>(wq + (__builtin_amdgcn_readlane(pack, j0 + u) & 127) * kCh);
-          float2 t = *p;
-          t.x += a[u] * g[u].x; t.y += a[u] * g[u].y;
-          *p = t;
+          const int j = (j0 + 8 + u) & 63;
+          gn[u] = go_one(go_rsrc, ch * 4, __builtin_amdgcn_readlane(pack, j) & ~127);
+          an[u] = par[2 * j];
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
       }
+      __builtin_amdgcn_sched_barrier(0);               // keep the requests above ahead of the updates below
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float* p = wq + (__builtin_amdgcn_readlane(pack, j0 + u) & 127) * kCh;
+        const float t0 = p[0], t1 = p[kWin * kCh];
+        p[0] = t0 + a[u].x * g[u];
+        p[kWin * kCh] = t1 + a[u].y * g[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
     }
-    // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
-    const int ch = lane & 31;
-    float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
-    for (int i = lane >> 5; i < kWinLines; i += 2) {
-      const int r = i / kWin, c = i - r * kWin;
-      const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
-      if (py < 0 || py >= Hl || px < 0 || px >= Wl) continue;
-      const float v = win[i * kCh + ch];
-      if (v != 0.f) unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
-    }
+  }
+  // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
+  float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
+  for (int i = half; i < kWinLines; i += 2) {
+    const int r = i / kWin, c = i - r * kWin;
+    const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
+    if (py < 0 || py >= Hl || px < 0 || px >= Wl) continue;
+    const float v = win[i * kCh + ch];
+    if (v != 0.f) unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
   }
 }
 
@@ -848,7 +847,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
   }
 }
 
-// workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks, claim counter: 4]
+// workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks: 4]
 // [chunk table: 4 * max_chunks][records: n_samples].  The level shapes live on the device, so the host
 // sizes the tables from a bound (bin_plan).
 struct BinPlan {
@@ -934,7 +933,7 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
                        n_chunks, B, H, L);
     hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
                        counts, rec, H, Nq, L, P);
-    const int tgrid = (int)min((int64_t)kTileWgs, (p.max_chunks + kTWaves - 1) / kTWaves);
+    const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
                        Nv, H, L, P, (int)(n_items * kCh * 4));
