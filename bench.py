@@ -57,9 +57,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-step", action="store_true",
                     help="also time the oracle port of the WHOLE step on a bounded sample (BEV 50x50; round-2 leg)")
-    ap.add_argument("--extra-configs", default="vidar_1_8_nusc_3future",
-                    help="comma-separated configs timed after the main one in the same run (short records under "
-                         "`configs`); the north star's target sentence names vidar_1_8_nusc_3future")
+    ap.add_argument("--extra-configs",
+                    default="vidar_1_8_nusc_3future,vidar_OpenScene_mini_full_3future,vidar_full_nusc_1future@2",
+                    help="comma-separated `config[@samples_per_gpu]` entries timed after the main one in the same run "
+                         "(short records under `configs`): BASELINE.json's other named configs -- the north star's "
+                         "target sentence names vidar_1_8_nusc_3future; OpenScene = 8 cameras; @2 = per-GPU batch 2")
     ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--extra-warmup", type=int, default=2)
     ap.add_argument("--cpu-baseline-only", choices=["ops", "step", "full"], help=argparse.SUPPRESS)
@@ -408,9 +410,9 @@ def ddp_info(ddp, world):
         return {"error": str(e)[:100]}
 
 
-def make_batch(cfg, args, rank, dev):
+def make_batch(cfg, args, rank, dev, spg=None):
     from vidar_amd.synthetic import fpn_features, make_sample
-    spg = args.samples_per_gpu
+    spg = spg or args.samples_per_gpu
     samples = [make_sample(seed=100 + rank * spg + i, queue_length=cfg["queue_length"],
                            future_frames=cfg["future_frames"], rays_per_frame=args.rays_per_frame,
                            num_cams=cfg["num_cams"], img_hw=cfg["img_hw"]) for i in range(spg)]
@@ -424,7 +426,7 @@ def make_batch(cfg, args, rank, dev):
     return batch
 
 
-def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers):
+def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None):
     """build the model of one named config, time `steps` training steps -> dict(elapsed, ops, ddp, cfg)"""
     from vidar_amd import gemm_tuning
     from vidar_amd import train as T
@@ -437,7 +439,7 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers)
     model = T.build_model(cfg).to(dev).train()
     ddp = T.wrap_ddp(model, local)
     opt = T.build_optimizer(model)
-    batch = make_batch(cfg, args, rank, dev)
+    batch = make_batch(cfg, args, rank, dev, spg)
     grouped = dist.is_available() and dist.is_initialized()
 
     def after_warmup():
@@ -491,11 +493,15 @@ def main():
     main_run = run_config(args.config, args, rank, local, world, dev, args.steps, args.warmup, with_markers=True)
     elapsed, ops, cfg = main_run["elapsed"], main_run["ops"], main_run["cfg"]
     extras = []
-    for name in [c for c in args.extra_configs.split(",") if c and c != args.config]:
-        r = run_config(name, args, rank, local, world, dev, args.extra_steps, args.extra_warmup, with_markers=False)
-        rec = {"config": name, "value": world * spg * args.extra_steps / r["elapsed"], "unit": "samples/s",
-               "ms_per_step": r["elapsed"] / args.extra_steps * 1e3, "steps": args.extra_steps,
-               "warmup": args.extra_warmup, "n_gpus": world, "global_batch": world * spg}
+    for entry in [c for c in args.extra_configs.split(",") if c and c != args.config]:
+        name, _, xs = entry.partition("@")
+        xspg = int(xs) if xs else spg
+        r = run_config(name, args, rank, local, world, dev, args.extra_steps, args.extra_warmup, with_markers=False,
+                       spg=xspg)
+        rec = {"config": name, "samples_per_gpu": xspg, "value": world * xspg * args.extra_steps / r["elapsed"],
+               "unit": "samples/s", "ms_per_step": r["elapsed"] / args.extra_steps * 1e3, "steps": args.extra_steps,
+               "warmup": args.extra_warmup, "n_gpus": world, "global_batch": world * xspg,
+               "cameras": r["cfg"]["num_cams"], "img_hw": list(r["cfg"]["img_hw"])}
         if r["ops"]:
             dn, dv = max(((k, v) for k, v in r["ops"].items() if not k.startswith(("dcn_", "affine_act"))),
                          key=lambda kv: kv[1]["total_ms"])

@@ -94,6 +94,19 @@ __device__ __forceinline__ void tri_scatter(float* __restrict__ gvol, const Tri&
   for (int c = 0; c < 8; ++c)
     if (t.o[c] >= 0) unsafeAtomicAdd(gvol + t.o[c], t.w[c] * g);
 }
+// the four corners with x-corner `cx` only.  fp32 global atomics cost per (instruction x 128-byte line touched)
+// (tools/micro/atomic_bench.hip): the backward kernels pair adjacent lanes on ONE waypoint -- even lane x0, odd lane
+// x0 + 1, neighbouring addresses of the x-fastest volume -- so an atomic instruction of 32 waypoints touches the lines
+// of 32 corners instead of 64: half the requests of a lane-per-waypoint scatter for the same 8 adds per waypoint.
+__device__ __forceinline__ void tri_scatter_x(float* __restrict__ gvol, const Tri& t, float g, int cx) {
+  if (g == 0.f) return;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int o = cx ? t.o[2 * c + 1] : t.o[2 * c];
+    const float w = cx ? t.w[2 * c + 1] : t.w[2 * c];
+    if (o >= 0) unsafeAtomicAdd(gvol + o, w * g);
+  }
+}
 
 __device__ __forceinline__ void waypoint(const Ray& r, int k, float step, float& sx, float& sy,
                                          float& sz) {
@@ -184,12 +197,12 @@ __global__ __launch_bounds__(kThreads) void ray_ce_bwd_kernel(
   float* gvol = grad_sigma + slice;
   const float lse = lse_in[r];
   if (lane == 0) tri_scatter(gvol, t0, g * (expf(tri_load(vol, t0) - lse) - 1.f));
-#pragma unroll
-  for (int j = 0; j < kPerLane; ++j) {
+  const int cx = lane & 1;
+  for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
     float sx, sy, sz;
-    waypoint(ray, lane + j * kWave, step, sx, sy, sz);
+    waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
     const Tri t = make_tri(sx, sy, sz, v);
-    if (!t.masked) tri_scatter(gvol, t, g * expf(tri_load(vol, t) - lse));
+    if (!t.masked) tri_scatter_x(gvol, t, g * expf(tri_load(vol, t) - lse), cx);
   }
 }
 
@@ -266,15 +279,15 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
   const float* vol = sigma + slice;
   float* gvol = grad_sigma + slice;
   const float pd = aux[(size_t)r * 3 + 0], pn = aux[(size_t)r * 3 + 1], lse = aux[(size_t)r * 3 + 2];
-#pragma unroll
-  for (int j = 0; j < kPerLane; ++j) {
+  const int cx = lane & 1;
+  for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
     float sx, sy, sz;
-    waypoint(ray, lane + j * kWave, step, sx, sy, sz);
+    waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
     const Tri t = make_tri(sx, sy, sz, v);
     if (t.masked) continue;
     const float p = expf(tri_load(vol, t) - lse);
     const float ind = dist_to(ray, sx, sy, sz) > pd ? 1.f : 0.f;
-    tri_scatter(gvol, t, g * pd * p * (ind - pn));
+    tri_scatter_x(gvol, t, g * pd * p * (ind - pn), cx);
   }
 }
 
