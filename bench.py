@@ -348,14 +348,20 @@ def kernel_rooflines(dev):
     add("chamferdist.knn_points_idx[30000x30000]", ms, 12 * 60000 + 12 * 30000,
         bound="fp32 VALU (9e8 pair evaluations, 8 flop each), not HBM",
         note=f"{9e8 / ms / 1e9:.2f} Tpairs/s = {9e8 * 8 / ms / 1e9:.1f} TFLOP/s fp32")
-    from vidar_amd.synthetic import msda_operands
+    from vidar_amd.synthetic import msda_operands, msda_operands_coherent
     fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
-    for name, B, shapes, Nq, P in (("TSA", 2, [(200, 200)], 40000, 4), ("SCA", 6, fpn, 10000, 8)):
-        value, sh, lsi, loc, w = msda_operands(0, B, shapes, Nq, P=P, device=dev)
+    # random reference points (no two queries share a line: the worst case for the caches) and, for the cross attention,
+    # spatially coherent queries like the ones the model produces (neighbouring BEV queries project next to each other)
+    for name, B, shapes, Nq, P, coherent in (("TSA", 2, [(200, 200)], 40000, 4, False), ("SCA", 6, fpn, 10000, 8, False),
+                                             ("SCA, coherent queries", 6, fpn, 10000, 8, True)):
+        value, sh, lsi, loc, w = (msda_operands_coherent(0, B, shapes, Nq, P=P, px=2.0, device=dev) if coherent
+                                  else msda_operands(0, B, shapes, Nq, P=P, device=dev))
         L = len(shapes); Nv = value.shape[1]
         go = torch.randn(B, Nq, 256, device=dev)
         add(f"msda_fwd[{name}]", hip_time(lambda: _msda_forward(value, sh, lsi, loc, w)),
-            msda_fwd_bytes(B, Nv, 8, 32, Nq, L, P), bound="L1/TA line rate (61 M corner lines), reported vs HBM")
+            msda_fwd_bytes(B, Nv, 8, 32, Nq, L, P),
+            bound="L1 (TCP) bandwidth: 61 M corner lines x 128 B through the vector caches, TA busy 79 % "
+                  "(profiles/r03_pmc_msda_sca); reported vs HBM")
         add(f"msda_bwd[{name}]", hip_time(lambda: _msda_backward(value, sh, lsi, loc, w, go)),
             msda_bwd_bytes(B, Nv, 8, 32, Nq, L, P))
     return rows

@@ -99,22 +99,14 @@ def bench_msda_coherent(which):
     """both scatter strategies of msda_bwd on spatially coherent queries (what the model produces:
     neighbouring BEV queries sample next to each other; the random reference points of `bench_msda`
     share no lines) + their agreement."""
-    from vidar_amd.synthetic import msda_operands
-    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_backward
+    from vidar_amd.synthetic import msda_operands_coherent
+    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_backward, _msda_forward
     fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
     for name, B, shapes, Nq, P, px in (("TSA-like", 2, [(200, 200)], 40000, 4, 1.0),
                                        ("SCA-like far (2 level-0 px between queries)", 6, fpn, 10000, 8, 2.0),
                                        ("SCA-like near (8 px)", 6, fpn, 10000, 8, 8.0)):
-        value, sh, lsi, loc, w = msda_operands(0, B, shapes, Nq, P=P)
-        L = len(shapes)
-        side = int(Nq ** 0.5)
-        q = torch.arange(Nq)
-        step = px / shapes[0][1]                                   # in normalised image units
-        base = torch.stack([(q % side) * step + 0.1, (q // side) * step * 0.5 + 0.1], -1)   # [Nq, 2]
-        g = torch.Generator().manual_seed(1)
-        off = (torch.rand(1, 1, 8, L, P, 2, generator=g) - 0.5) * 0.02      # per (head, level, point), shared by queries
-        loc = (base[None, :, None, None, None, :] + off).expand(B, Nq, 8, L, P, 2).contiguous().clamp(0.0, 0.999)
-        value, sh, lsi, loc, w = value.cuda(), sh.cuda(), lsi.cuda(), loc.cuda(), w.cuda()
+        value, sh, lsi, loc, w = msda_operands_coherent(0, B, shapes, Nq, P=P, px=px, device="cuda")
+        report(f"msda_fwd {name}", timeit(lambda: _msda_forward(value, sh, lsi, loc, w)))
         go = torch.randn(B, Nq, 256, device="cuda")
         outs = {}
         for binned in (False, True):

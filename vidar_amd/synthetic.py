@@ -162,6 +162,23 @@ def msda_operands(seed, B, shapes, Nq, H=8, C=32, P=4, spread=0.05, device="cpu"
     return tuple(t.to(device) for t in (value, sh, lsi, loc, w))
 
 
+def msda_operands_coherent(seed, B, shapes, Nq, H=8, C=32, P=4, px=2.0, device="cpu"):
+    """Operands whose queries are spatially COHERENT, like the ones the model produces (neighbouring BEV queries
+    project next to each other): query q sits `px` level-0 pixels right of query q-1 on a sqrt(Nq)-wide raster, every
+    (head, level, point) adds its own fixed offset of up to +-1 % of the image.  Same layout as msda_operands."""
+    import torch
+    value, sh, lsi, _, w = msda_operands(seed, B, shapes, Nq, H=H, C=C, P=P)
+    L = len(shapes)
+    side = int(Nq ** 0.5)
+    q = torch.arange(Nq)
+    step = px / shapes[0][1]                                   # in normalised image units
+    base = torch.stack([(q % side) * step + 0.1, (q // side) * step * 0.5 + 0.1], -1)   # [Nq, 2]
+    g = torch.Generator().manual_seed(seed + 1)
+    off = (torch.rand(1, 1, H, L, P, 2, generator=g) - 0.5) * 0.02
+    loc = (base[None, :, None, None, None, :] + off).expand(B, Nq, H, L, P, 2).contiguous().clamp(0.0, 0.999)
+    return tuple(t.to(device) for t in (value, sh, lsi, loc, w))
+
+
 def dense_rays(Fn, Z, Y, X, device="cpu"):
     """end points of the dense-loss rays: the voxel centres of a (Y/4, X/4, Z/4) sub-grid per frame
     (dense_heads/vidar_head_base.py:606-630) -> (pts [Fn*n, 3] in voxel units, frame index [Fn*n])"""
