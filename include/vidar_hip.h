@@ -143,6 +143,9 @@ int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
  *   value [B,Nv,H,C] f32 (C must be 32), spatial_shapes [L,2] i64 (h,w), level_start_index [L] i64,
  *   sampling_loc [B,Nq,H,L,P,2] f32 in [0,1] (x,y), attn_weight [B,Nq,H,L,P] f32, out [B,Nq,H*C].
  * im2col_step of the reference API has no meaning here and is dropped at the Python layer.
+ * Limits (VIDAR_ERR_BAD_ARG otherwise): C == 32, L <= 16, L*P <= 64, and `value` smaller than 4 GiB
+ * (B*Nv*H*C*4 < 2^32: corner lines are addressed with 32-bit byte offsets from `value`).
+ * A sample outside its level, or with a NaN location, contributes nothing (zero output / gradients).
  * bwd: grad_value is zeroed by the call then accumulated with fp32 atomics; grad_sampling_loc and
  * grad_attn_weight are fully written (the reference expects pre-zeroed buffers, function.py:146-148).
  * ------------------------------------------------------------------------- */
@@ -156,7 +159,7 @@ int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
  *                       into the workspace, accumulated per tile in LDS and flushed with one atomic per
  *                       non-zero window line (see csrc/msda.hip).  The workspace needs
  *                       vidar_msda_bwd_workspace_bytes(...) bytes (0 = shape not supported by this
- *                       strategy: more than 16 levels or >= 2^31 samples), is scratch (no state survives the
+ *                       strategy: >= 2^31 samples or grad_out of 2 GiB and more), is scratch (no state survives the
  *                       call) and must stay alive until the stream has run the call.
  * Both give the same result up to fp32 summation order. */
 size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P);

@@ -38,13 +38,28 @@ def test_driver_flags_parse_and_defaults_are_single_gpu():
 
 
 def test_pmc_traffic_is_backed_by_committed_profiles():
+    """`roofline.traffic` = profiles/pmc_traffic.json, which tools/make_pmc_traffic.py derives from the committed PMC
+    summaries with the FETCH_SIZE calibration applied (gfx950 reports half of the fetched bytes, also for this
+    library's random 128-byte line gathers: tools/micro/fetch_calib.hip)."""
     sys.path.insert(0, str(ROOT))
     import bench
     nbytes, src = bench.pmc_traffic("msda_bwd[L=4,P=8]")
     assert nbytes and nbytes > 8.7e8                        # at least the algorithmic bytes
-    files = [p for p in (ROOT / "profiles").glob("r02_pmc_*_SIZE_kbench_msda.csv")]
-    assert len(files) == 2 and "r02_pmc_" in src
+    assert "r03_pmc_msda_sca" in src and "calibration" in src
+    for f in ("pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv"):
+        assert (ROOT / "profiles" / "r03_pmc_msda_sca" / f).exists()
     assert bench.pmc_traffic("no such kernel") == (None, None)
+    # the json is reproducible from the csv files
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "make_pmc_traffic.py"), "profiles/r03_pmc_msda_sca",
+                        "profiles/r03_pmc_FETCH_SIZE_calibration.csv", "profiles/r03_pmc_WRITE_SIZE_calibration.csv"],
+                       capture_output=True, text=True, cwd=ROOT, timeout=60)
+    made = json.loads(r.stdout)
+    have = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+    assert made == have
+    cal = have["calibration"]
+    assert abs(cal["fetch_factor"] - 2.0) < 0.02 and abs(cal["write_factor"] - 1.0) < 0.01
+    bwd = have["msda_bwd[L=4,P=8]"]
+    assert abs(bwd["bytes"] - (bwd["fetch_bytes"] + bwd["write_bytes"])) < 1 and bwd["ratio"] > 1
 
 
 def test_cpu_baseline_leg_reports_a_bounded_sample():
