@@ -163,12 +163,6 @@ int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
  *                       call) and must stay alive until the stream has run the call.
  * Both give the same result up to fp32 summation order. */
 size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P);
-/* The binned backward runs its grad_sampling_loc / grad_attn_weight gather (L1 bound) concurrently with the sort and
- * the LDS-bound accumulation of grad_value: it is forked onto a library-owned side stream after everything already
- * queued on `stream` and joined before the call's work on `stream` ends -- callers see ordinary stream semantics
- * (the reference's op is synchronous on the current stream).  0 switches the overlap off (everything on `stream`);
- * returns the previous setting.  Process-wide; results are identical either way. */
-int vidar_msda_set_bwd_overlap(int on);
 int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, const float* grad_out, float* grad_value,

@@ -235,31 +235,3 @@ def test_one_hot_destination_pixel_many_chunks():
     b = F._msda_backward(value.cuda(), sh.cuda(), lsi, loc.cuda(), w.cuda(), go, binned=False)
     for u, v in zip(a, b):
         torch.testing.assert_close(u, v, rtol=2e-3, atol=2e-3 * max(1.0, float(v.abs().max())))
-
-
-def test_side_stream_gather_is_invisible_to_the_caller():
-    """the binned backward forks its grad_loc / grad_w gather onto a library-owned side stream and joins it before
-    the call's work on the caller's stream ends: same results with the overlap off, on a non-default stream too,
-    and the outputs are complete for work queued on the caller's stream right after the call (no explicit sync)."""
-    from vidar_amd._lib import lib
-    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
-    from vidar_amd.synthetic import msda_operands
-    value, sh, lsi, loc, w = msda_operands(3, 2, [(40, 60), (20, 30)], 3000, P=4, device="cuda")
-    go = torch.randn(2, 3000, 256, device="cuda")
-    prev = lib().vidar_msda_set_bwd_overlap(0)
-    try:
-        ref = F._msda_backward(value, sh, lsi, loc, w, go, binned=True)
-        lib().vidar_msda_set_bwd_overlap(1)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                got = F._msda_backward(value, sh, lsi, loc, w, go, binned=True)
-                sums = [g.double().sum() for g in got]          # queued right behind the call, same stream
-        side.synchronize()
-        for a, b, total in zip(got, ref, sums):
-            scale = max(1.0, float(b.abs().max()))
-            torch.testing.assert_close(a, b, rtol=3e-4, atol=3e-5 * scale)
-            assert abs(float(total) - float(b.double().sum())) <= 1e-3 * max(1.0, float(b.double().abs().sum()))
-    finally:
-        lib().vidar_msda_set_bwd_overlap(prev)

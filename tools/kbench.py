@@ -130,14 +130,9 @@ def bench_msda(which):
         ms = timeit(lambda: _msda_forward(value, sh, lsi, loc, w))
         report(f"msda_fwd {name}", ms, fwd_bytes)
         go = torch.randn(B, Nq, 256, device="cuda")
-        from vidar_amd._lib import lib
         for binned in (False, True):
             ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=binned))
             report(f"msda_bwd {name} binned={binned}", ms, fwd_bytes + 4 * (B * Nq * 256 + B * Nv * 256 + B * Nq * 8 * L * P * 3))
-        prev = lib().vidar_msda_set_bwd_overlap(0)        # A/B: the gather on the caller's stream instead of the side stream
-        ms = timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=True))
-        lib().vidar_msda_set_bwd_overlap(prev)
-        report(f"msda_bwd {name} binned=True, no side stream", ms)
 
 
 def bench_msda_sca(which):

@@ -878,39 +878,9 @@ inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
   return B < 0 || Nv < 0 || H <= 0 || C != kCh || Nq < 0 || L <= 0 || P <= 0 || L * P > kMaxLP;
 }
 
-// The two big kernels of the binned backward are bound by different units -- the accumulate kernel by the LDS pipe,
-// the grad_loc / grad_w gather by the vector L1 (TA) -- and do not depend on each other: the gather is forked onto a
-// library-owned side stream at the start of the call (after everything already queued on the caller's stream) and
-// joined before the call's work on the caller's stream ends, so both share the CUs.  Inputs are only read and the
-// outputs are complete when the caller's stream passes the join: callers see ordinary stream semantics.
-int g_msda_bwd_overlap = 1;
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
-  SideStream() {
-    ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-  }
-};
-inline SideStream* side_stream() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  static thread_local SideStream* per_device[16] = {};      // created on first use, on the device that is current
-  if (!per_device[dev]) per_device[dev] = new SideStream();
-  return per_device[dev]->ok ? per_device[dev] : nullptr;
-}
-
 }  // namespace
 
 extern "C" {
-
-int vidar_msda_set_bwd_overlap(int on) {
-  const int prev = g_msda_bwd_overlap;
-  g_msda_bwd_overlap = on ? 1 : 0;
-  return prev;
-}
 
 static int msda_fwd_launch(const float* value, const int64_t* spatial_shapes,
                            const int64_t* level_start_index, const float* sampling_loc,
@@ -953,20 +923,6 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     int* n_chunks = (int*)(ws + p.off_chunks);
     int4* desc = (int4*)(ws + p.off_desc);
     int* rec = (int*)(ws + p.off_rec);
-    const int nblocks = (int)((n_items + kItems - 1) / kItems);
-    const int grid = ((nblocks + 7) / 8) * 8;
-    const size_t lds = rec_lds_bytes(L * P);
-    SideStream* side = g_msda_bwd_overlap ? side_stream() : nullptr;
-    if (side) {
-      hipError_t ef = hipEventRecord(side->fork, s);
-      if (ef == hipSuccess) ef = hipStreamWaitEvent(side->stream, side->fork, 0);
-      if (ef != hipSuccess) return (int)ef;
-      hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, side->stream, value, spatial_shapes,
-                         level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
-                         grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
-      ef = hipEventRecord(side->join, side->stream);
-      if (ef != hipSuccess) return (int)ef;
-    }
     hipError_t e = hipMemsetAsync(counts, 0, p.off_desc, s);
     if (e != hipSuccess) return (int)e;
     const dim3 bgrid((Nq + kBinQ - 1) / kBinQ, B * H * L);
@@ -981,14 +937,12 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
                        Nv, H, L, P, (int)(n_items * kCh * 4));
-    if (side) {
-      const hipError_t ej = hipStreamWaitEvent(s, side->join, 0);
-      if (ej != hipSuccess) return (int)ej;
-    } else {
-      hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
-                         level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
-                         grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
-    }
+    const int nblocks = (int)((n_items + kItems - 1) / kItems);
+    const int grid = ((nblocks + 7) / 8) * 8;
+    const size_t lds = rec_lds_bytes(L * P);
+    hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
+                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
     return vidar_last_error();
   }
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
