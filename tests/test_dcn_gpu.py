@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("N,C,Cout,H,W,stride", [(2, 8, 6, 9, 11, 1), (1, 16, 16, 12, 10, 2), (1, 3, 4, 5, 5, 1),
-                                                 (2, 40, 8, 58, 100, 1)])      # stage-3 feature map size
+                                                 (2, 40, 8, 58, 100, 1),       # stage-3 feature map size
+                                                 (1, 20, 4, 6, 2, 1)])         # narrowest image of the pair-load kernels
 def test_dcn_fwd_bwd(N, C, Cout, H, W, stride):
     from vidar_amd.plugin.backbones import modulated_deform_conv2d
     g = torch.Generator().manual_seed(N * 100 + C)
@@ -30,6 +31,44 @@ def test_dcn_fwd_bwd(N, C, Cout, H, W, stride):
     for a, b, nm in zip(got, gref, ["x", "offset", "mask", "weight", "bias"]):
         torch.testing.assert_close(a.cpu().double(), b, rtol=2e-4, atol=2e-4 * max(1.0, float(b.abs().max())),
                                    msg=lambda m: nm + ": " + m)
+
+
+def test_one_column_image_equals_the_same_image_padded_with_a_zero_column():
+    """W == 1 takes the scalar-load kernels (the pair-load ones need two columns; the grid_sample oracle cannot
+    express a one-column image): zero padding makes it equal to the W == 2 image with an empty second column."""
+    from vidar_amd.plugin.backbones import modulated_deform_conv2d
+    g = torch.Generator().manual_seed(11)
+    x1 = torch.randn(2, 6, 5, 1, generator=g).cuda().requires_grad_(True)
+    off = (torch.randn(2, 18, 5, 1, generator=g) * 0.8).cuda().requires_grad_(True)
+    mask = torch.rand(2, 9, 5, 1, generator=g).cuda().requires_grad_(True)
+    wgt = torch.randn(4, 6, 3, 3, generator=g).cuda()
+    gout = torch.randn(2, 4, 5, 1, generator=g).cuda()
+    out1 = modulated_deform_conv2d(x1, off, mask, wgt, None, stride=1, padding=1)
+    g1 = torch.autograd.grad((out1 * gout).sum(), [x1, off, mask])
+    x2 = torch.cat([x1.detach(), torch.zeros_like(x1)], -1).requires_grad_(True)               # [.., 5, 2]
+    pad = lambda t, v: torch.cat([t.detach(), torch.full_like(t, v)], -1).requires_grad_(True)  # second output column unused
+    off2, mask2 = pad(off, 0.0), pad(mask, 0.0)
+    out2 = modulated_deform_conv2d(x2, off2, mask2, wgt, None, stride=1, padding=1)
+    torch.testing.assert_close(out2[..., :1], out1, rtol=1e-5, atol=1e-5)
+    g2 = torch.autograd.grad((out2[..., :1] * gout).sum(), [x2, off2, mask2])
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b[..., :1], rtol=1e-4, atol=1e-5)
+
+
+def test_im2col_far_and_nan_offsets_contribute_nothing():
+    """a tap sampled outside the image, or at a NaN location, is zero padding (not NaN x 0)"""
+    from vidar_amd.plugin.backbones import modulated_deform_conv2d
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 17, 7, 9, generator=g).cuda()
+    off = torch.zeros(1, 18, 7, 9); off[:, :6] = 50.0; off[:, 6:8, 2:4] = float("nan")
+    mask = torch.ones(1, 9, 7, 9)
+    wgt = torch.randn(5, 17, 3, 3, generator=g)
+    out = modulated_deform_conv2d(x, off.cuda(), mask.cuda(), wgt.cuda(), None, stride=1, padding=1)
+    assert torch.isfinite(out).all()
+    keep = torch.ones(9); keep[:3] = 0                      # taps 0-2 left the image everywhere
+    ref = torch.nn.functional.conv2d(x, (wgt * keep.view(1, 1, 3, 3)).cuda(), padding=1)
+    ok = torch.ones(7, 9, dtype=torch.bool); ok[2:4] = False       # rows whose 4th tap is NaN lose that tap too
+    torch.testing.assert_close(out[..., ok.cuda()], ref[..., ok.cuda()], rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("N,C,H,W,stride", [(2, 19, 9, 11, 1), (1, 32, 29, 50, 1), (2, 5, 12, 10, 2)])

@@ -100,6 +100,67 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
   }
 }
 
+// im2col, pair-load form (W >= 2).  The four corners of a tap are two horizontally adjacent PAIRS: one 8-byte load
+// per row instead of two 4-byte loads (the kernel sits on the vector memory pipe: 4 gathers + 1 store per column
+// element before, 2 + 1 now), and everything that does not depend on the channel -- clamped pair index, the four
+// weights times the mask, with the zero padding folded into the weights -- is computed once per (pixel, tap) and
+// reused for the kCP channels of the thread's group.  The pair starts at column c0 = clamp(w0, 0, W-2): for
+// w0 == -1 the right corner is element 0 of the pair, for w0 == W-1 the left corner is element 1.
+constexpr int kCP = 16;
+typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));
+
+struct PairFoot {
+  int top[kMaxTaps], bot[kMaxTaps];          // element index of the pair in the top / bottom row
+  float wt0[kMaxTaps], wt1[kMaxTaps], wb0[kMaxTaps], wb1[kMaxTaps];
+};
+
+__device__ __forceinline__ PairFoot pair_footprints(const float* __restrict__ offset, const float* __restrict__ mask,
+                                                    int n, int p, const Conv& g) {
+  const Foot f = footprints(offset, mask, n, p, g);
+  PairFoot o;
+#pragma unroll
+  for (int t = 0; t < kMaxTaps; ++t) {
+    const Bil& q = f.q[t];
+    const float m = q.in ? f.m[t] : 0.f;
+    const int c0 = min(max(q.w0, 0), g.W - 2);
+    const int r0 = min(max(q.h0, 0), g.H - 1), r1 = min(max(q.h0 + 1, 0), g.H - 1);
+    // weights of the left / right corner, then their place in the loaded pair
+    const float wl = (q.l ? 1.f - q.lw : 0.f), wr = (q.r ? q.lw : 0.f);
+    const float a0 = q.w0 == c0 ? wl : (q.w0 < c0 ? wr : 0.f);          // w0 == -1: the right corner is element 0
+    const float a1 = q.w0 == c0 ? wr : (q.w0 > c0 ? wl : 0.f);          // w0 == W-1: the left corner is element 1
+    const float ht = (q.t ? 1.f - q.lh : 0.f) * m, hb = (q.b ? q.lh : 0.f) * m;
+    o.top[t] = r0 * g.W + c0; o.bot[t] = r1 * g.W + c0;
+    // a sample outside the image (or NaN) contributes nothing: select, not a product with 0
+    o.wt0[t] = q.in ? ht * a0 : 0.f; o.wt1[t] = q.in ? ht * a1 : 0.f;
+    o.wb0[t] = q.in ? hb * a0 : 0.f; o.wb1[t] = q.in ? hb * a1 : 0.f;
+  }
+  return o;
+}
+
+// grid: (ceil(P/256), ceil(C/kCP), N)
+__global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ offset,
+                                                              const float* __restrict__ mask,
+                                                              float* __restrict__ cols, Conv g) {
+  const int P = g.Ho * g.Wo, K = g.kh * g.kw;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int n = blockIdx.z, c0 = blockIdx.y * kCP;
+  const PairFoot f = pair_footprints(offset, mask, n, p, g);
+  for (int c = c0; c < min(c0 + kCP, g.C); ++c) {
+    const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
+    float* out = cols + ((size_t)n * g.C + c) * K * P + p;
+#pragma unroll
+    for (int t = 0; t < kMaxTaps; ++t) {
+      if (t < K) {
+        const pair_t a = *reinterpret_cast<const pair_t*>(im + f.top[t]);
+        const pair_t b = *reinterpret_cast<const pair_t*>(im + f.bot[t]);
+        out[(size_t)t * P] = f.wt0[t] * a.x + f.wt1[t] * a.y + f.wb0[t] * b.x + f.wb1[t] * b.y;
+      }
+    }
+  }
+}
+
 // grad wrt input: scatter grad_cols * mask * corner weights (atomics); grid as im2col.  Lanes are
 // neighbouring pixels, so a wave instruction touches only 2-3 lines (atomics cost per instruction x line).
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ grad_cols,
@@ -256,7 +317,33 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(
   const float m = mask[((size_t)n * K + t) * P + p];
   const Bil q = bil(h, w, g.H, g.W);
   float gh = 0.f, gw = 0.f, gm = 0.f;
-  if (q.in) {
+  if (q.in && g.W >= 2) {
+    // pair loads like dcn_im2col_pair_kernel: per row one 8-byte load; the corner -> pair-element map and the zero
+    // padding are folded into 12 coefficients computed once per (pixel, tap)
+    const float hh = 1.f - q.lh, hw = 1.f - q.lw;
+    const int c0 = min(max(q.w0, 0), g.W - 2);
+    const int top = min(max(q.h0, 0), g.H - 1) * g.W + c0, bot = min(max(q.h0 + 1, 0), g.H - 1) * g.W + c0;
+    const float tl = (q.t && q.l) ? 1.f : 0.f, tr = (q.t && q.r) ? 1.f : 0.f;
+    const float bl = (q.b && q.l) ? 1.f : 0.f, br = (q.b && q.r) ? 1.f : 0.f;
+    const bool same = q.w0 == c0, left = q.w0 < c0;          // left: w0 == -1 (right corner is element 0)
+    auto e0 = [&](float cl, float cr) { return same ? cl : (left ? cr : 0.f); };
+    auto e1 = [&](float cl, float cr) { return same ? cr : (left ? 0.f : cl); };
+    const float m_t0 = e0(hh * hw * tl, hh * q.lw * tr), m_t1 = e1(hh * hw * tl, hh * q.lw * tr);
+    const float m_b0 = e0(q.lh * hw * bl, q.lh * q.lw * br), m_b1 = e1(q.lh * hw * bl, q.lh * q.lw * br);
+    const float h_t0 = e0(-hw * tl, -q.lw * tr), h_t1 = e1(-hw * tl, -q.lw * tr);
+    const float h_b0 = e0(hw * bl, q.lw * br), h_b1 = e1(hw * bl, q.lw * br);
+    const float w_t0 = e0(-hh * tl, hh * tr), w_t1 = e1(-hh * tl, hh * tr);
+    const float w_b0 = e0(-q.lh * bl, q.lh * br), w_b1 = e1(-q.lh * bl, q.lh * br);
+    for (int c = 0; c < g.C; ++c) {
+      const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
+      const float gc = grad_cols[(((size_t)n * g.C + c) * K + t) * P + p];
+      const pair_t a = *reinterpret_cast<const pair_t*>(im + top);
+      const pair_t b = *reinterpret_cast<const pair_t*>(im + bot);
+      gm += gc * (m_t0 * a.x + m_t1 * a.y + m_b0 * b.x + m_b1 * b.y);
+      gh += gc * (h_t0 * a.x + h_t1 * a.y + h_b0 * b.x + h_b1 * b.y);
+      gw += gc * (w_t0 * a.x + w_t1 * a.y + w_b0 * b.x + w_b1 * b.y);
+    }
+  } else if (q.in) {
     const float hh = 1.f - q.lh, hw = 1.f - q.lw;
     for (int c = 0; c < g.C; ++c) {
       const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
@@ -292,8 +379,12 @@ int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask,
   if (dcn_bad(N, g)) return VIDAR_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (kh * kw > kMaxTaps) return VIDAR_ERR_BAD_ARG;
-  hipLaunchKernelGGL(dcn_im2col_kernel, dim3((Ho * Wo + 255) / 256, (C + kCG - 1) / kCG, N), dim3(256),
-                     0, (hipStream_t)stream, x, offset, mask, cols, g);
+  if (W >= 2)
+    hipLaunchKernelGGL(dcn_im2col_pair_kernel, dim3((Ho * Wo + 255) / 256, (C + kCP - 1) / kCP, N), dim3(256),
+                       0, (hipStream_t)stream, x, offset, mask, cols, g);
+  else
+    hipLaunchKernelGGL(dcn_im2col_kernel, dim3((Ho * Wo + 255) / 256, (C + kCG - 1) / kCG, N), dim3(256),
+                       0, (hipStream_t)stream, x, offset, mask, cols, g);
   return vidar_last_error();
 }
 
