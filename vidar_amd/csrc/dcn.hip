@@ -138,6 +138,12 @@ __device__ __forceinline__ PairFoot pair_footprints(const float* __restrict__ of
 }
 
 // grid: (ceil(P/256), ceil(C/kCP), N)
+// Counters (profiles/r03_pmc_dcn): the waves of this kernel spend 91 % of their cycles in s_waitcnt at 7 % VALU --
+// loads and stores share gfx9's vmcnt counter and complete out of order with respect to each other, so the compiler
+// has to drain the previous channel's nine column stores before it may consume the next channel's gathers: the
+// store acknowledgement latency is exposed once per channel (measured 0.41 ms for 641 MB of columns, the same as the
+// scalar-load kernel it replaces: the instruction count was never the limit).  A hand-pipelined channel loop does
+// not help for the same reason (every wait became vmcnt(0)) and cost 100 more VGPRs.
 __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ offset,
                                                               const float* __restrict__ mask,
