@@ -138,12 +138,31 @@ __device__ __forceinline__ PairFoot pair_footprints(const float* __restrict__ of
 }
 
 // grid: (ceil(P/256), ceil(C/kCP), N)
-// Counters (profiles/r03_pmc_dcn): the waves of this kernel spend 91 % of their cycles in s_waitcnt at 7 % VALU --
-// loads and stores share gfx9's vmcnt counter and complete out of order with respect to each other, so the compiler
-// has to drain the previous channel's nine column stores before it may consume the next channel's gathers: the
-// store acknowledgement latency is exposed once per channel (measured 0.41 ms for 641 MB of columns, the same as the
-// scalar-load kernel it replaces: the instruction count was never the limit).  A hand-pipelined channel loop does
-// not help for the same reason (every wait became vmcnt(0)) and cost 100 more VGPRs.
+// Counters (profiles/r03_pmc_dcn): with the channel loop outside (18 gathers, then 9 column stores per channel) the
+// waves spent 91 % of their cycles in s_waitcnt at 7 % VALU -- loads and stores share gfx9's vmcnt counter and
+// complete out of order with respect to each other, so the compiler has to drain the previous stores before it may
+// consume the next gathers: the store acknowledgement latency is exposed once per (load batch, store batch) round.
+// Hence the TAP loop is outside: per tap the 2 x kCP pair loads of all channels of the group are in flight together
+// (plus the next tap's offsets and mask), then kCP stores -- 9 rounds per thread instead of 16, each twice as big.
+struct TapFoot { unsigned top, bot; float wt0, wt1, wb0, wb1; };
+
+__device__ __forceinline__ TapFoot tap_foot(float h, float w, float m, const Conv& g) {
+  const Bil q = bil(h, w, g.H, g.W);
+  const int c0 = min(max(q.w0, 0), g.W - 2);
+  const int r0 = min(max(q.h0, 0), g.H - 1), r1 = min(max(q.h0 + 1, 0), g.H - 1);
+  // weights of the left / right corner, then their place in the loaded pair
+  const float wl = (q.l ? 1.f - q.lw : 0.f), wr = (q.r ? q.lw : 0.f);
+  const float a0 = q.w0 == c0 ? wl : (q.w0 < c0 ? wr : 0.f);          // w0 == -1: the right corner is element 0
+  const float a1 = q.w0 == c0 ? wr : (q.w0 > c0 ? wl : 0.f);          // w0 == W-1: the left corner is element 1
+  const float ht = (q.t ? 1.f - q.lh : 0.f) * m, hb = (q.b ? q.lh : 0.f) * m;
+  TapFoot f;
+  f.top = (unsigned)(r0 * g.W + c0) * 4u; f.bot = (unsigned)(r1 * g.W + c0) * 4u;      // byte offsets inside a plane
+  // a sample outside the image (or NaN) contributes nothing: select, not a product with 0
+  f.wt0 = q.in ? ht * a0 : 0.f; f.wt1 = q.in ? ht * a1 : 0.f;
+  f.wb0 = q.in ? hb * a0 : 0.f; f.wb1 = q.in ? hb * a1 : 0.f;
+  return f;
+}
+
 __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ offset,
                                                               const float* __restrict__ mask,
@@ -151,19 +170,30 @@ __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __res
   const int P = g.Ho * g.Wo, K = g.kh * g.kw;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
-  const int n = blockIdx.z, c0 = blockIdx.y * kCP;
-  const PairFoot f = pair_footprints(offset, mask, n, p, g);
-  for (int c = c0; c < min(c0 + kCP, g.C); ++c) {
-    const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
-    float* out = cols + ((size_t)n * g.C + c) * K * P + p;
+  const int n = blockIdx.z, c0 = blockIdx.y * kCP, nc = min(kCP, g.C - c0);
+  const int py = p / g.Wo, px = p % g.Wo;
+  const size_t plane = (size_t)g.H * g.W, KP = (size_t)K * P;
+  const char* im = reinterpret_cast<const char*>(x + ((size_t)n * g.C + c0) * plane);       // wave-uniform bases
+  float* out = cols + ((size_t)n * g.C + c0) * KP + p;
+  const float* off_n = offset + (size_t)n * 2 * K * P + p;
+  const float* msk_n = mask + (size_t)n * K * P + p;
+  float oh = off_n[0], ow = off_n[P], m = msk_n[0];
+  for (int t = 0; t < K; ++t) {
+    const int i = t / g.kw, j = t - i * g.kw;
+    const TapFoot f = tap_foot(py * g.stride - g.pad + i * g.dil + oh, px * g.stride - g.pad + j * g.dil + ow, m, g);
+    pair_t a[kCP], b[kCP];
 #pragma unroll
-    for (int t = 0; t < kMaxTaps; ++t) {
-      if (t < K) {
-        const pair_t a = *reinterpret_cast<const pair_t*>(im + f.top[t]);
-        const pair_t b = *reinterpret_cast<const pair_t*>(im + f.bot[t]);
-        out[(size_t)t * P] = f.wt0[t] * a.x + f.wt1[t] * a.y + f.wb0[t] * b.x + f.wb1[t] * b.y;
-      }
+    for (int c = 0; c < kCP; ++c) {
+      const char* pl = im + (size_t)(c < nc ? c : 0) * plane * 4;
+      a[c] = *reinterpret_cast<const pair_t*>(pl + f.top);
+      b[c] = *reinterpret_cast<const pair_t*>(pl + f.bot);
     }
+    if (t + 1 < K) {                                     // the next tap's offsets and mask ride in the same round
+      oh = off_n[(size_t)(2 * t + 2) * P]; ow = off_n[(size_t)(2 * t + 3) * P]; m = msk_n[(size_t)(t + 1) * P];
+    }
+#pragma unroll
+    for (int c = 0; c < kCP; ++c)
+      if (c < nc) out[(size_t)c * KP + (size_t)t * P] = f.wt0 * a[c].x + f.wt1 * a[c].y + f.wb0 * b[c].x + f.wb1 * b[c].y;
   }
 }
 
