@@ -209,30 +209,15 @@ __global__ __launch_bounds__(kThreads) void lr_prob_bwd_kernel(const float* __re
   const float go = grad_prob[((size_t)b * Q + q) * kZ + z];
   // d/d(1-p_k) of prod * pc  = prod/(1-p_k) * pc ; guarded against (1-p_k) == 0
   const float gp = go * pr * pc;
-  // Loads and atomics share gfx9's vmcnt counter and complete out of order with respect to each other, so a loop of
-  // "sample, then scatter" drains the atomics of iteration k before it may consume the loads of iteration k+1.
-  // Rounds of kRound waypoints: all their taps are sampled first, then all are scattered -- a quarter of the drains.
-  constexpr int kRound = 4;
-  for (int k0 = ks; k0 < g.G; k0 += 4 * kRound) {
-    Tap t[kRound];
-    float x[kRound];
-    bool on[kRound];
-#pragma unroll
-    for (int u = 0; u < kRound; ++u) {
-      const int k = k0 + 4 * u;
-      float nx, ny, len;
-      waypoint(c, g, min(k, g.G - 1), nx, ny, len);
-      on[u] = k < g.G && len < c.len_c;
-      t[u] = make_tap(nx, ny, g);
-      x[u] = on[u] ? tap_load1(map, t[u], z) : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < kRound; ++u) {
-      if (on[u]) {
-        const float p = act_f(x[u], g.act);
-        const float gs = (1.f - p) > 0.f ? -gp / (1.f - p) * act_d(x[u], p, g.act) : 0.f;
-        tap_scatter1(gmap, t[u], z, gs);
-      }
+  for (int k = ks; k < g.G; k += 4) {
+    float nx, ny, len;
+    waypoint(c, g, k, nx, ny, len);
+    if (len < c.len_c) {
+      const Tap t = make_tap(nx, ny, g);
+      const float x = tap_load1(map, t, z);
+      const float p = act_f(x, g.act);
+      const float gs = (1.f - p) > 0.f ? -gp / (1.f - p) * act_d(x, p, g.act) : 0.f;
+      tap_scatter1(gmap, t, z, gs);
     }
   }
   if (ks == 0) tap_scatter1(gmap, tc, z, go * pr * act_d(xc, pc, g.act));
@@ -291,27 +276,15 @@ __global__ __launch_bounds__(kThreads) void lr_gather_bwd_kernel(
   const size_t o = ((size_t)b * Q + q) * kZ + z;
   const float f = feat[o];
   const float s = grad_feat[o] / (msum[o] + g.eps);
-  constexpr int kRound = 4;                            // sample kRound waypoints, then scatter them (see lr_prob_bwd_kernel)
-  for (int k0 = ks; k0 < g.G; k0 += 4 * kRound) {
-    Tap t[kRound];
-    float m[kRound], av[kRound];
-    bool on[kRound];
-#pragma unroll
-    for (int u = 0; u < kRound; ++u) {
-      const int k = k0 + 4 * u;
-      float nx, ny, len;
-      waypoint(c, g, min(k, g.G - 1), nx, ny, len);
-      on[u] = k < g.G && len < c.bound;
-      t[u] = make_tap(nx, ny, g);
-      m[u] = on[u] ? tap_load1(pm, t[u], z) : 0.f;
-      av[u] = on[u] ? tap_load1(am, t[u], z) : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < kRound; ++u) {
-      if (on[u]) {
-        tap_scatter1(gam, t[u], z, s * m[u]);
-        tap_scatter1(gpm, t[u], z, s * (av[u] - f));
-      }
+  for (int k = ks; k < g.G; k += 4) {
+    float nx, ny, len;
+    waypoint(c, g, k, nx, ny, len);
+    if (len < c.bound) {
+      const Tap t = make_tap(nx, ny, g);
+      const float m = tap_load1(pm, t, z);
+      const float av = tap_load1(am, t, z);
+      tap_scatter1(gam, t, z, s * m);
+      tap_scatter1(gpm, t, z, s * (av - f));
     }
   }
 }

@@ -198,22 +198,11 @@ __global__ __launch_bounds__(kThreads) void ray_ce_bwd_kernel(
   const float lse = lse_in[r];
   if (lane == 0) tri_scatter(gvol, t0, g * (expf(tri_load(vol, t0) - lse) - 1.f));
   const int cx = lane & 1;
-  // 32 waypoints per pass, a lane pair per waypoint.  Loads and atomics share gfx9's vmcnt counter and complete out
-  // of order with respect to each other ("sample, then scatter" drains the atomics of one pass before the samples of
-  // the next can be consumed): two passes are sampled, then both are scattered.
-  for (int j = 0; j < 2 * kPerLane; j += 2) {
-    Tri t[2];
-    float gs[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float sx, sy, sz;
-      waypoint(ray, (lane >> 1) + (j + u) * (kWave / 2), step, sx, sy, sz);
-      t[u] = make_tri(sx, sy, sz, v);
-      gs[u] = t[u].masked ? 0.f : g * expf(tri_load(vol, t[u]) - lse);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (!t[u].masked) tri_scatter_x(gvol, t[u], gs[u], cx);
+  for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
+    float sx, sy, sz;
+    waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
+    const Tri t = make_tri(sx, sy, sz, v);
+    if (!t.masked) tri_scatter_x(gvol, t, g * expf(tri_load(vol, t) - lse), cx);
   }
 }
 
@@ -291,24 +280,14 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
   float* gvol = grad_sigma + slice;
   const float pd = aux[(size_t)r * 3 + 0], pn = aux[(size_t)r * 3 + 1], lse = aux[(size_t)r * 3 + 2];
   const int cx = lane & 1;
-  for (int j = 0; j < 2 * kPerLane; j += 2) {          // two passes of 32 waypoints sampled, then scattered (see ray_ce_bwd_kernel)
-    Tri t[2];
-    float gs[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float sx, sy, sz;
-      waypoint(ray, (lane >> 1) + (j + u) * (kWave / 2), step, sx, sy, sz);
-      t[u] = make_tri(sx, sy, sz, v);
-      gs[u] = 0.f;
-      if (!t[u].masked) {
-        const float p = expf(tri_load(vol, t[u]) - lse);
-        const float ind = dist_to(ray, sx, sy, sz) > pd ? 1.f : 0.f;
-        gs[u] = g * pd * p * (ind - pn);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-      if (!t[u].masked) tri_scatter_x(gvol, t[u], gs[u], cx);
+  for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
+    float sx, sy, sz;
+    waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
+    const Tri t = make_tri(sx, sy, sz, v);
+    if (t.masked) continue;
+    const float p = expf(tri_load(vol, t) - lse);
+    const float ind = dist_to(ray, sx, sy, sz) > pd ? 1.f : 0.f;
+    tri_scatter_x(gvol, t, g * pd * p * (ind - pn), cx);
   }
 }
 
