@@ -43,7 +43,6 @@ struct HostGrad {
   void commit(int, int vid, double, double dt, double P, double) {
     grad[vid] += (double)(float)(dl_dd * (dt * (P - S_total)));
   }
-  void tick(int) {}
 };
 
 int host_dvr_render(const float* sigma, const float* origin, const float* points,
@@ -92,9 +91,7 @@ int host_dvxlr_render(const float* sigma, const float* sigma_regul, const float*
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < M; ++c) {
       est_steps[(size_t)n * M + c] = estimate_steps(load_ray(origin, points, tindex, n, c, M, g), g);
-      // through the staging path of the kernels (samples collected for kStageEvery steps, then written together)
-      float stage[kStageCap * 3];
-      dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g, stage, 1);
+      dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g);
     }
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < M; ++c) {

@@ -116,7 +116,6 @@ struct GradScatter {
     const double g = dl_dd * (dt * (P - S_total));
     if (g != 0.0) unsafeAtomicAdd(grad + vid, (float)g);
   }
-  __device__ __forceinline__ void tick(int) {}
 };
 
 template <int kBlock>
@@ -172,11 +171,10 @@ __global__ __launch_bounds__(kBlock) void dvxlr_march_kernel(
     const float* __restrict__ points, const float* __restrict__ tindex,
     float* __restrict__ pred_dist, float* __restrict__ gt_dist, float* __restrict__ indices, int M,
     Vol g) {
-  __shared__ float s_stage[kStageCap * 3 * kBlock];       // staged samples, planes of kBlock lanes (dvr_march.h)
   const int n = blockIdx.y;
   const int c = pick_ray<kBlock>(origin, points, tindex, n, M, g);
   if (c >= M) return;
-  dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g, s_stage + threadIdx.x, kBlock);
+  dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g);
 }
 
 // grid: (ceil(M/4), N), 256 threads = 4 rays.  Rows are 8-byte aligned (1026 floats, aligned base).

@@ -130,7 +130,6 @@ VIDAR_DEV double march(const RayIn& r, const Vol& g, Sink& sink) {
       if (!sink.sample(qx, qy, qz, d, last_d)) break;
     }
     last_d = d;
-    sink.tick((int)step);                      // every lane still marching passes here together
   }
   sink.finish();
   return len;
@@ -195,13 +194,11 @@ struct Integrator {
   VIDAR_DEV void finish() {
     if (MODE == kRoundedMerged && pending) { commit(uvid, ud, udt); pending = false; }
   }
-  VIDAR_DEV void tick(int step) { emit.tick(step); }
   // after finish(): count = k, p_out = Tprev, max_d = dprev, pred = d0 + S
 };
 
 struct NoEmit {
   VIDAR_DEV void commit(int, int, double, double, double, double) {}
-  VIDAR_DEV void tick(int) {}
 };
 
 // dvxlr staging: while a lane walks its ray it parks each sample in the ray's own `indices` row
@@ -214,51 +211,18 @@ struct Parked {
   float dt, vid, w_prev;
 };
 
-// Staged variant (stage != nullptr, device): loads and stores share gfx9's vmcnt counter and complete out of order
-// with respect to each other, so a store parked at every step makes the NEXT step's sigma load wait for that store's
-// acknowledgement.  The samples of up to kStageEvery steps are therefore collected in LDS (three 4-byte planes per
-// entry, lane-interleaved: conflict free) and written out together, by all lanes still marching at once
-// (`tick`), and once more at the end (`flush`).  A step commits at most one sample, `finish` one more.
-constexpr int kStageEvery = 8;
-constexpr int kStageCap = kStageEvery + 1;
-
 struct RowStager {
-  Parked* __restrict__ slot;  // &idx_row[3k] for the next sample that goes to memory
+  Parked* __restrict__ slot;  // &idx_row[3k] for the next commit
   double true_len;
   int k_surface = -1;
-  float* stage = nullptr;     // this lane's column of the staging planes, or nullptr: store directly
-  int stride = 0;             // lanes per plane
-  int nbuf = 0;
   VIDAR_DEV void commit(int k, int vid, double d, double dt, double, double w_prev) {
     Parked p;
     p.dt = (float)dt;
     p.vid = (float)vid;
     p.w_prev = (float)w_prev;
-    if (stage == nullptr) {
-      *slot = p;
-      ++slot;
-    } else {
-      float* e = stage + (size_t)nbuf * 3 * stride;
-      e[0] = p.dt; e[stride] = p.vid; e[2 * stride] = p.w_prev;
-      ++nbuf;
-    }
+    *slot = p;
+    ++slot;
     if (k_surface < 0 && d >= true_len) k_surface = k;    // dvxlr_v2.cu:408-424
-  }
-  VIDAR_DEV void flush() {
-    if (stage == nullptr) return;
-    for (int i = 0; i < kStageCap; ++i) {
-      if (i < nbuf) {
-        const float* e = stage + (size_t)i * 3 * stride;
-        Parked p;
-        p.dt = e[0]; p.vid = e[stride]; p.w_prev = e[2 * stride];
-        slot[i] = p;
-      }
-    }
-    slot += nbuf;
-    nbuf = 0;
-  }
-  VIDAR_DEV void tick(int step) {
-    if ((step % kStageEvery) == kStageEvery - 1) flush();
   }
 };
 
@@ -278,8 +242,7 @@ VIDAR_DEV void decode_stash(float stash, int& count, int& k_surface, bool& nan_t
 VIDAR_DEV void dvxlr_march_ray(const float* __restrict__ sigma, const float* __restrict__ origin,
                                const float* __restrict__ points, const float* __restrict__ tindex,
                                float* __restrict__ pred_dist, float* __restrict__ gt_dist,
-                               float* __restrict__ indices, int n, int c, int M, const Vol& g,
-                               float* stage = nullptr, int stage_stride = 0) {
+                               float* __restrict__ indices, int n, int c, int M, const Vol& g) {
   constexpr int L = kDvxlrMaxD;
   const size_t row = (size_t)n * M + c;
   float* idr = indices + row * L * 3;
@@ -288,7 +251,6 @@ VIDAR_DEV void dvxlr_march_ray(const float* __restrict__ sigma, const float* __r
   if (r.valid) {
     RowStager st;
     st.slot = reinterpret_cast<Parked*>(idr);
-    st.stage = stage; st.stride = stage_stride;
     {
       const double rx = r.xe - r.xo, ry = r.ye - r.yo, rz = r.ze - r.zo;
       st.true_len = sqrt(rx * rx + ry * ry + rz * rz);
@@ -297,7 +259,6 @@ VIDAR_DEV void dvxlr_march_ray(const float* __restrict__ sigma, const float* __r
     Integrator<kRoundedMerged, kDvxlrMaxD, RowStager> a(sigma + ((size_t)n * g.T + r.ts) * vol, g.Y, g.X,
                                                         st);
     const double len = march<kRoundedMerged>(r, g, a);
-    st.flush();
     if (a.k > 0) {
       pred = (float)(a.d0 + a.S);
       gt = (float)fmin(len, a.dprev);
