@@ -208,6 +208,12 @@ int vidar_drop_add_ln_bwd_f32(const float* grad_y, const float* sum_in, const fl
                               void* stream);
 size_t vidar_drop_add_ln_bwd_workspace_bytes(int64_t rows); /* scratch for the per-workgroup affine-gradient partials */
 
+/* Column sums of a row-major [rows, cols] fp32 matrix: out[c] = sum_r x[r, c] -- the bias gradient of the Linear
+ * layers on the path (what autograd computes with a generic `sum(0)` for every nn.Linear the reference's modules
+ * own, e.g. temporal_self_attention.py:93-98, spatial_cross_attention.py:229-232; mmcv FFN [3P]).  `out` [cols] is
+ * zeroed and fully written by the call.  cols must be a multiple of 4 whose quarter is a power of two (<= 4096). */
+int vidar_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* stream);
+
 /* ---------------------------------------------------------------------------
  * BEV-encoder bookkeeping for F frames at once.  Replaces BEVFormerEncoder.point_sampling
  * (projects/mmdet3d_plugin/bevformer/modules/encoder.py:96-156) and the visible-query rebatch index of

@@ -64,3 +64,39 @@ def test_other_widths_take_the_torch_path():
     x = torch.randn(3, 64, device="cuda"); r = torch.randn(3, 64, device="cuda")
     assert not can_fuse_norm(norm, x)
     torch.testing.assert_close(drop_add_layernorm(x, r, norm, 0.5, training=False), norm(x + r))
+
+
+@pytest.mark.parametrize("rows,cols", [(40000, 256), (184950, 256), (46080, 512), (40000, 64), (7, 16), (1, 4), (0, 128),
+                                       (100003, 128)])
+def test_colsum_matches_fp64_column_sums(rows, cols):
+    """vidar_colsum_f32: the bias gradient of the Linear layers (sum over rows), against an fp64 sum"""
+    import ctypes
+    from vidar_amd._lib import lib, check, ptr, stream_of
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).cuda()
+    out = torch.full((cols,), float("nan"), device="cuda")
+    check(lib().vidar_colsum_f32(ptr(x), ptr(out), ctypes.c_int64(rows), cols, stream_of(x)), "colsum")
+    ref = x.double().sum(0)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=2e-4 * max(1.0, rows ** 0.5))
+    assert lib().vidar_colsum_f32(ptr(x), ptr(out), ctypes.c_int64(rows), 12, stream_of(x)) != 0    # 3 groups: not a power of two
+
+
+def test_bricks_linear_gradients_equal_nn_linear():
+    """plugin.bricks.Linear = nn.Linear with the column-sum kernel for the bias gradient (same parameters / keys)"""
+    from vidar_amd.plugin.bricks import Linear
+    torch.manual_seed(0)
+    a = Linear(256, 128).cuda(); b = nn.Linear(256, 128).cuda()
+    b.load_state_dict(a.state_dict())
+    assert list(a.state_dict()) == list(b.state_dict())
+    x = torch.randn(3, 5000, 256, device="cuda")
+    xa = x.clone().requires_grad_(True); xb = x.clone().requires_grad_(True)
+    gy = torch.randn(3, 5000, 128, device="cuda")
+    ya, yb = a(xa), b(xb)
+    assert torch.equal(ya, yb)
+    ya.backward(gy); yb.backward(gy)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-3)
+    odd = Linear(256, 80).cuda()                               # 20 column groups: torch's own backward
+    odd(x).sum().backward()
+    assert torch.isfinite(odd.bias.grad).all()

@@ -161,9 +161,71 @@ __global__ __launch_bounds__(256) void affine_grad_reduce_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Column sums of a row-major [rows, cols] matrix: the bias gradient of a Linear layer, grad_b = sum over rows of
+// grad_y (torch's generic reduction runs this shape at ~1.2 TB/s: 134 calls, ~5 ms per training step).
+// One resident grid (one 1024-thread workgroup per CU-sized slab): thread = (float4 column group, row lane), rows are
+// read as whole coalesced lines, the row lanes of a workgroup meet in LDS and the workgroup adds ONE partial row to the
+// zeroed output (256 workgroups x cols atomics).
+// ---------------------------------------------------------------------------------------------
+constexpr int kColsumThreads = 1024;
+
+__global__ __launch_bounds__(kColsumThreads) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                int64_t rows, int cols) {
+  __shared__ float4 s_acc[kColsumThreads];
+  const int groups = cols >> 2;                                // float4 column groups, a power of two <= 1024
+  const int g = threadIdx.x & (groups - 1), r0 = threadIdx.x / groups, rstep = kColsumThreads / groups;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t row_lo = (int64_t)blockIdx.x * per, row_hi = min(rows, row_lo + per);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  int64_t r = row_lo + r0;
+  for (; r + rstep < row_hi; r += 2 * rstep) {                 // two independent rows in flight per thread
+    const float4 v0 = reinterpret_cast<const float4*>(x + r * cols)[g];
+    const float4 v1 = reinterpret_cast<const float4*>(x + (r + rstep) * cols)[g];
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+  }
+  if (r < row_hi) {
+    const float4 v0 = reinterpret_cast<const float4*>(x + r * cols)[g];
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+  }
+  s_acc[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  __syncthreads();
+  for (int half = rstep >> 1; half >= 1; half >>= 1) {         // tree over the row lanes of a column group
+    if (r0 < half) {
+      const float4 o = s_acc[threadIdx.x + half * groups];
+      float4& m = s_acc[threadIdx.x];
+      m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+    }
+    __syncthreads();
+  }
+  if (r0 == 0 && row_lo < row_hi) {
+    const float4 t = s_acc[threadIdx.x];
+    unsafeAtomicAdd(out + 4 * g, t.x); unsafeAtomicAdd(out + 4 * g + 1, t.y);
+    unsafeAtomicAdd(out + 4 * g + 2, t.z); unsafeAtomicAdd(out + 4 * g + 3, t.w);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int vidar_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* stream) {
+  VIDAR_ENTER();
+  // cols: a multiple of 4 whose float4 groups are a power of two and fit one workgroup row (4 .. 4096)
+  const int groups = cols / 4;
+  if (rows < 0 || cols <= 0 || cols % 4 != 0 || (groups & (groups - 1)) != 0 || groups > kColsumThreads)
+    return VIDAR_ERR_BAD_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)cols, s);
+  if (e != hipSuccess) return (int)e;
+  if (rows == 0) return 0;
+  const int64_t rows_per_pass = kColsumThreads / groups;
+  const int grid = (int)min((int64_t)256, (rows + rows_per_pass - 1) / rows_per_pass);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)grid), dim3(kColsumThreads), 0, s, x, out, rows, cols);
+  return vidar_last_error();
+}
+
 
 int vidar_drop_add_ln_fwd_f32(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
                               float* sum_out, float* mean_out, float* rstd_out, int64_t rows, int C, float p, float eps,

@@ -10,6 +10,7 @@ import torch
 from ..utils.host import const_tensor, to_device_async
 import torch.nn as nn
 
+from ..bricks import Linear
 from ..registry import HEADS
 from .vidar_head_base import ViDARHeadBase
 
@@ -27,9 +28,9 @@ class ViDARHeadV1(ViDARHeadBase):
         assert len(per_frame_loss_weight) == self.pred_frame_num
         branch = []
         for _ in range(self.num_pred_fcs):
-            branch += [nn.Linear(self.embed_dims, self.embed_dims), nn.LayerNorm(self.embed_dims),
+            branch += [Linear(self.embed_dims, self.embed_dims), nn.LayerNorm(self.embed_dims),
                        nn.ReLU(inplace=True)]
-        branch.append(nn.Linear(self.embed_dims, self.pred_frame_num * self.num_pred_height))
+        branch.append(Linear(self.embed_dims, self.pred_frame_num * self.num_pred_height))
         head = nn.Sequential(*branch)
         self.bev_pred_head = nn.ModuleList(
             [copy.deepcopy(head) for _ in range(self.transformer.decoder.num_layers)])

@@ -160,7 +160,9 @@ class BEVFormerEncoder(TransformerLayerSequence):
             sca_index = visible_query_index(bev_mask)    # once per pass instead of once per layer
         shift_ref_2d = ref_2d.clone() + shift[:, None, None, :]
         bev_query = bev_query.permute(1, 0, 2)
-        bev_pos = bev_pos.permute(1, 0, 2)
+        # [Q, bs, C] view of a [bs, C, H, W] map -> [bs, Q, C]: made contiguous ONCE per pass; the six layers add it
+        # to the queries twice each, and an add against the channel-strided view runs at a third of the rate
+        bev_pos = bev_pos.permute(1, 0, 2).contiguous()
         bs, len_bev, num_bev_level, _ = ref_2d.shape
         if prev_bev is not None:
             prev_bev = prev_bev.permute(1, 0, 2)

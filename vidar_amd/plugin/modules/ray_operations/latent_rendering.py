@@ -13,6 +13,7 @@ import torch.nn as nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from ...bricks import Linear
 from ...registry import ATTENTION
 from ...._lib import lib, check, ptr, stream_of, TIMER
 
@@ -111,12 +112,12 @@ class LatentRendering(nn.Module):
         self.act = act
         branch = []
         for _ in range(num_pred_fcs):
-            branch += [nn.Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True)]
-        branch.append(nn.Linear(embed_dims, pred_height))
+            branch += [Linear(embed_dims, embed_dims), nn.LayerNorm(embed_dims), nn.ReLU(inplace=True)]
+        branch.append(Linear(embed_dims, pred_height))
         self.unsup_raymarching_head = nn.Sequential(*branch)
         self.pred_height = pred_height
-        self.lora_a = nn.Linear(embed_dims, embed_dims // reduction)
-        self.lora_b = nn.Linear(embed_dims // reduction, embed_dims)
+        self.lora_a = Linear(embed_dims, embed_dims // reduction)
+        self.lora_b = Linear(embed_dims // reduction, embed_dims)
         if pred_height != 16 or embed_dims // reduction != pred_height:
             # the reference's view(bs, pred_height, -1, ...) (:151-154) allows more LoRA channels per
             # height bin; every released config uses 16/16 and the kernels are specialised for it

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..bricks import drop_add_layernorm, constant_init, xavier_init
+from ..bricks import Linear, drop_add_layernorm, constant_init, xavier_init
 from ..registry import ATTENTION, build_attention
 from ._attn_common import init_deformable_offsets
 from .multi_scale_deformable_attn_function import MultiScaleDeformableAttnFunction_fp32, fused_deform_attn
@@ -87,7 +87,7 @@ class SpatialCrossAttention(nn.Module):
         self.deformable_attention = build_attention(deformable_attention)
         self.embed_dims = embed_dims
         self.num_cams = num_cams
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = Linear(embed_dims, embed_dims)
         self.batch_first = batch_first
         self.init_weight()
 
@@ -174,9 +174,9 @@ class MSDeformableAttention3D(nn.Module):
         self.num_levels = num_levels
         self.num_heads = num_heads
         self.num_points = num_points
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.sampling_offsets = Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = Linear(embed_dims, embed_dims)
         self.init_weights()
 
     def init_weights(self):

@@ -8,7 +8,7 @@ import torch
 from ..utils.host import const_tensor
 import torch.nn as nn
 
-from ..bricks import can_fuse_norm, drop_add_layernorm, constant_init, xavier_init
+from ..bricks import Linear, can_fuse_norm, drop_add_layernorm, constant_init, xavier_init
 from ..registry import ATTENTION, TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE
 from ._attn_common import init_deformable_offsets
 from .custom_base_transformer_layer import MyCustomBaseTransformerLayer
@@ -124,10 +124,10 @@ class PredictionMSDeformableAttention(nn.Module):
         self.num_levels = num_levels
         self.num_heads = num_heads
         self.num_points = num_points
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, embed_dims)
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.sampling_offsets = Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = Linear(embed_dims, embed_dims)
+        self.output_proj = Linear(embed_dims, embed_dims)
         self.init_weights()
 
     def init_weights(self):
