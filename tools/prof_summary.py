@@ -6,14 +6,16 @@ import sqlite3
 import sys
 
 
-OWN = ("msda_", "dcn_", "affine_act", "lr_", "ray_", "knn", "sca_", "drop_add_ln", "dvr", "dvxlr", "vidar_",
-       "rows_", "bev_", "latent_")
+OWN = ("msda_", "dcn_", "affine_act", "affine_grad", "lr_", "ray_", "knn", "sca_", "drop_add_ln", "dvr", "dvxlr", "vidar_",
+       "rows_", "bev_", "latent_", "colsum")
 
 
 def category(name):
     """library GEMMs (Tensile kernels of hipBLASLt / rocBLAS) / MIOpen convolutions / this library's HIP kernels /
     torch eager kernels / the rest (fills, copies, RCCL)"""
     short = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    if "(anonymous namespace)::" in name and "at::" not in name and "rocprim" not in name:
+        return "vidar_amd HIP kernels"          # every kernel of libvidar_hip.so lives in an anonymous namespace
     if short.startswith("Cijk_") or "Cijk_" in short[:40]:
         return "library GEMM (hipBLASLt / rocBLAS)"
     if short.startswith(("miopen", "igemm_", "batched_transpose", "naive_conv", "gridwise_", "SubTensorOp", "MIOpen")) \

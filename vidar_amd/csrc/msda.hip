@@ -15,7 +15,8 @@
 // the 32 head channels as a float4, so every corner fetch of an item is one 128-byte line and a
 // wave covers 8 items (= all 8 heads of one query) per instruction.  Sampling locations and
 // weights of the 32 items of a workgroup are staged through LDS with fully coalesced loads
-// (they are contiguous in HBM) and re-read as broadcasts.  Workgroups are remapped so that each
+// (they are contiguous in HBM); one thread per sample turns them into a 32-byte record (corner weights
+// and byte offsets) that the item's 8 lanes re-read as broadcasts.  Workgroups are remapped so that each
 // XCD walks a contiguous band of queries: neighbouring BEV queries sample neighbouring pixels, so
 // a band keeps its slice of `value` resident in that XCD's private 4 MiB L2.
 // Backward: two grad_value strategies, chosen per call through the `workspace` argument -- the destination-binned
@@ -68,37 +69,6 @@ __device__ __forceinline__ Corner corners(float x, float y, int Hl, int Wl, int6
   c.o01 = (t && r) ? base + ((int64_t)h0 * Wl + w1) * row_stride : -1;
   c.o10 = (b && l) ? base + ((int64_t)h1 * Wl + w0) * row_stride : -1;
   c.o11 = (b && r) ? base + ((int64_t)h1 * Wl + w1) * row_stride : -1;
-  return c;
-}
-
-__device__ __forceinline__ float4 ld4(const float* __restrict__ p, int64_t o) {
-  return o >= 0 ? *reinterpret_cast<const float4*>(p + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// Branch-free variant for the gather kernels: corner offsets are 32-bit (relative to the batch element, the
-// host checks Nv*H*C < 2^31), always in range (clamped), and a corner outside the level carries weight / mask 0
-// instead of a predicated load -- four unconditional 16-byte loads per sample, no exec-mask juggling and no
-// 64-bit multiplies in the inner loop.
-struct Corner32 {
-  int o00, o01, o10, o11;
-  float w00, w01, w10, w11;      // bilinear weights, 0 for corners outside the level
-  float m00, m01, m10, m11;      // 1 / 0 validity
-  float lh, lw;
-};
-
-__device__ __forceinline__ Corner32 corners32(float x, float y, int Hl, int Wl, int base, int row_stride) {
-  Corner32 c;
-  const int h0 = (int)floorf(y), w0 = (int)floorf(x);
-  c.lh = y - h0; c.lw = x - w0;
-  const float hh = 1.f - c.lh, hw = 1.f - c.lw;
-  const float t = h0 >= 0 ? 1.f : 0.f, b = h0 + 1 <= Hl - 1 ? 1.f : 0.f;
-  const float l = w0 >= 0 ? 1.f : 0.f, r = w0 + 1 <= Wl - 1 ? 1.f : 0.f;
-  c.m00 = t * l; c.m01 = t * r; c.m10 = b * l; c.m11 = b * r;
-  c.w00 = hh * hw * c.m00; c.w01 = hh * c.lw * c.m01; c.w10 = c.lh * hw * c.m10; c.w11 = c.lh * c.lw * c.m11;
-  const int r0 = max(h0, 0) * Wl, r1 = min(h0 + 1, Hl - 1) * Wl;
-  const int c0 = max(w0, 0), c1 = min(w0 + 1, Wl - 1);
-  c.o00 = base + (r0 + c0) * row_stride; c.o01 = base + (r0 + c1) * row_stride;
-  c.o10 = base + (r1 + c0) * row_stride; c.o11 = base + (r1 + c1) * row_stride;
   return c;
 }
 
