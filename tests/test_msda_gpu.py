@@ -131,8 +131,15 @@ def test_full_size_matches_oracle(name, scatter):
     # the forward, grad_value and grad_w are continuous there and are compared everywhere.
     wh = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float64).view(1, 1, 1, len(shapes), 1, 2)
     pixel = loc.double() * wh - 0.5
-    kink = ((pixel - pixel.round()).abs() < 1e-4).any(-1, keepdim=True).expand_as(loc)
-    assert float(kink.double().mean()) < 0.05      # mostly clamped out-of-image locations (zero gradient anyway)
+    # only samples that can contribute (inside the zero-padding border, with the same margin) need the exemption:
+    # outside, both sides have a zero gradient.  The exempted share is asserted, not just bounded: a window of
+    # +-1e-4 px around the integers on two axes is 4e-4 of the live samples -- a kernel that is wrong near cell
+    # borders cannot hide in it.
+    live = ((pixel > -1 - 1e-4) & (pixel < wh + 1e-4)).all(-1, keepdim=True)
+    kink = (((pixel - pixel.round()).abs() < 1e-4).any(-1, keepdim=True) & live).expand_as(loc)
+    share = float(kink[..., 0].double().sum() / live.double().sum())
+    print(f"{name}: {int(kink[..., 0].sum())} of {int(live.sum())} live samples exempted from the grad_loc check ({share:.2e})")
+    assert 2e-4 < share < 8e-4, share
     got[1] = torch.where(kink, rl, got[1])
     for g, r, nm in zip(got, (rv, rl, rw), ["grad_value", "grad_loc", "grad_w"]):
         scale = max(1.0, float(r.abs().max()))
@@ -195,11 +202,13 @@ def test_fused_operand_preparation_matches_the_reference_tensor_program(case):
     # samples within fp32 rounding of a pixel boundary: d/d offset is one-sided there (see the full-size test)
     wh = torch.tensor([[w_, h_] for h_, w_ in shapes], dtype=torch.float64).view(1, 1, 1, L, 1, 2)
     pixel = loc.detach() * wh - 0.5
-    kink = ((pixel - pixel.round()).abs() < 1e-4).any(-1, keepdim=True).expand_as(loc)      # [bs*Qn,Nq,H,L,P,2]
+    live = ((pixel > -1 - 1e-4) & (pixel < wh + 1e-4)).all(-1, keepdim=True)
+    kink = (((pixel - pixel.round()).abs() < 1e-4).any(-1, keepdim=True) & live).expand_as(loc)   # [bs*Qn,Nq,H,L,P,2]
+    # small cases: the expected share is 4e-4 of the live samples, a handful in absolute terms
+    assert float(kink[..., 0].double().sum()) <= max(8.0, 2e-3 * float(live.double().sum()))
     if mode == 0:        # back to the raw layout [bs, Nq, H, Qn, L, P, 2]
         kink = kink.view(bs, Qn, Nq, H, L, P, 2).permute(0, 2, 3, 1, 4, 5, 6)
     kink = kink.reshape(got[1].shape)
-    assert float(kink.double().mean()) < 0.01
     got[1] = torch.where(kink, gwant[1], got[1])
     for a, b, nm in zip(got, gwant, ["grad_value", "grad_off_raw", "grad_logit_raw"]):
         scale = max(1.0, float(b.abs().max()))
