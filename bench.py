@@ -1,15 +1,21 @@
-"""bench.py -- train samples/s of ViDAR's hot path (6-cam FPN features -> BEV encode ->
+"""bench.py -- train samples/s of ViDAR's hot path (6-cam images -> ResNet101-DCNv2 + FPN -> BEV encode ->
 latent render -> occupancy head -> ray-march / chamfer losses -> backward -> AdamW) on N MI355X.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU, DDP gradient all-reduce over RCCL.  Prints ONE JSON line on rank 0 with the
-driver contract fields plus `roofline` (dominant HIP kernel, timed live with HIP events on the
-launch stream inside the timed region) and `cpu_baseline` (the CPU oracle port of the same step on a
-bounded sample, rank 0 / N=1 only).  A "sample" = one 5-frame x 6-camera sequence (global batch =
-number of GPUs, the reference asserts 1 sample per GPU: detectors/vidar.py:306)."""
+One process per GPU, DDP gradient all-reduce over RCCL.  Prints ONE JSON line on rank 0 (the last line of
+its stdout) with the driver contract fields plus
+  `roofline`         the dominant HIP kernel of the SURVEY 8(a) path, timed live with HIP events on the launch stream
+                     inside the timed region; `traffic` = calibrated PMC bytes (profiles/pmc_traffic.json);
+  `configs`          short records of BASELINE.json's other named configs, timed in the same process (every N);
+  `ddp`              DDP's bucket accounting incl. the buckets it rebuilds after the first step (N > 1);
+  `roofline_kernels` per-kernel rooflines at the BASELINE shapes (dvr family up to the c4 stress shape, MSDA, KNN; N = 1);
+  `cpu_baseline`     op-level, full-size CPU rows of the oracle port next to the GPU's own times (rank 0, N = 1, a
+                     child process outside the timed region).
+A "sample" = one 5-frame x 6-camera sequence (global batch = number of GPUs x --samples-per-gpu; the reference asserts
+1 sample per GPU: detectors/vidar.py:306)."""
 from __future__ import annotations
 
 import argparse
