@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 // weights times the mask, with the zero padding folded into the weights -- is computed once per (pixel, tap) and
 // reused for the kCP channels of the thread's group.  The pair starts at column c0 = clamp(w0, 0, W-2): for
 // w0 == -1 the right corner is element 0 of the pair, for w0 == W-1 the left corner is element 1.
-constexpr int kCP = 16;
+#ifndef VIDAR_DCN_CP
+#define VIDAR_DCN_CP 16          // channels per thread; 8 needs 52 instead of 85 VGPRs and no scalar spills (tools/tune_dcn_cp.sh)
+#endif
+constexpr int kCP = VIDAR_DCN_CP;
 typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));
 
 struct PairFoot {
