@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 // reused for the kCP channels of the thread's group.  The pair starts at column c0 = clamp(w0, 0, W-2): for
 // w0 == -1 the right corner is element 0 of the pair, for w0 == W-1 the left corner is element 1.
 #ifndef VIDAR_DCN_CP
-#define VIDAR_DCN_CP 16          // channels per thread; 8 needs 52 instead of 85 VGPRs and no scalar spills (tools/tune_dcn_cp.sh)
+#define VIDAR_DCN_CP 16          // channels per thread; 8 needs 52 instead of 85 VGPRs and no scalar spills (tools/staged_variants.sh)
 #endif
 constexpr int kCP = VIDAR_DCN_CP;
 typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));

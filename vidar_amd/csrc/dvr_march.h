@@ -152,6 +152,7 @@ struct Integrator {
 
   VIDAR_DEV Integrator(const float* s, int Y_, int X_, Emit& e) : sig(s), Y(Y_), X(X_), emit(e) {}
 
+#ifndef VIDAR_DVR_PIPELINED_SIGMA
   VIDAR_DEV void commit(int vid, double d, double dt) {
     const double sg = (double)sig[vid];
     double w_prev = 0.0;                       // W_{k-1} = T_{k-1} (d_k - d_{k-1})
@@ -169,6 +170,32 @@ struct Integrator {
     dprev = d;
     ++k;
   }
+#else
+  // Same arithmetic, same order per sample -- but the density of sample k is only CONSUMED by commit k+1 (the
+  // transmittance T_k first matters for W_k = T_k (d_{k+1} - d_k)), so its load has a whole traversal step to
+  // arrive instead of stalling the lane right after it is issued; the last sample's density is never needed.
+  float sg_fly = 0.f;                          // density of sample k-1, in flight
+  double dt_fly = 0.0;
+  VIDAR_DEV void commit(int vid, double d, double dt) {
+    double w_prev = 0.0;                       // W_{k-1} = T_{k-1} (d_k - d_{k-1})
+    if (k == 0) {
+      d0 = d;
+    } else {
+      const double sg = (double)sg_fly;
+      csd = (k == 1) ? sg * dt_fly : csd + sg * dt_fly;
+      Tprev = (double)expf((float)(-csd));
+      w_prev = Tprev * (d - dprev);
+      S += w_prev;
+    }
+    emit.commit(k, vid, d, dt, S, w_prev);
+    // issued after the last read of the previous density, so that the load can land in the very register that
+    // carries it to the next commit (a copy at the end of the block would wait for it)
+    sg_fly = sig[vid];
+    dt_fly = dt;
+    dprev = d;
+    ++k;
+  }
+#endif
 
   VIDAR_DEV bool sample(int x, int y, int z, double d, double last_d) {
     const int vid = (z * Y + y) * X + x;
