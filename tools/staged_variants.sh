@@ -20,7 +20,7 @@ run() {   # name, hipcc flags, pytest selection, kbench target, grep pattern of 
 
 echo "=================== default build"
 python -m vidar_amd.build > /dev/null 2>&1
-timeout 300 python tools/kbench.py dvr dcn 2>&1 | grep -i "render\|im2col" | cut -c1-160
+timeout 300 python tools/kbench.py dvr dcn 2>&1 | grep -i "render\|im2col\|col2im" | cut -c1-160
 
 # dvr family: a sample's density is consumed one commit later (dvr_march.h) -- bit-identical arithmetic, the load gets a
 # whole traversal step to arrive; expect the most at <= 1 wave per SIMD (30 k rays), where nothing else hides it
@@ -28,6 +28,10 @@ run dvr_pipe "-DVIDAR_DVR_PIPELINED_SIGMA" "tests/test_dvr_gpu.py tests/test_ful
 # DCN im2col: 8 channels per thread = 52 VGPRs, no scalar spills, 8 waves per SIMD (16: 85 / 27 / 5)
 run dcn_cp8 "-DVIDAR_DCN_CP=8" "tests/test_dcn_gpu.py" dcn "im2col"
 run dcn_cp4 "-DVIDAR_DCN_CP=4" "tests/test_dcn_gpu.py" dcn "im2col"
+# DCN col2im, offset / mask gradient: the channel loop keeps 3 loads in flight and waits 256 times in a row (0.144 ms
+# per call = 256 x one memory latency); the loads of 4 / 8 channels issued together (74 / 128 VGPRs, 6 / 4 waves)
+run dcn_coord4 "-DVIDAR_DCN_COORD_BATCH=4" "tests/test_dcn_gpu.py" dcn "col2im"
+run dcn_coord8 "-DVIDAR_DCN_COORD_BATCH=8" "tests/test_dcn_gpu.py" dcn "col2im"
 
 python -m vidar_amd.build > /dev/null 2>&1
 echo "default build restored"

@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 #define VIDAR_DCN_CP 16          // channels per thread; 8 needs 52 instead of 85 VGPRs and no scalar spills (tools/staged_variants.sh)
 #endif
 constexpr int kCP = VIDAR_DCN_CP;
+#ifndef VIDAR_DCN_COORD_BATCH
+#define VIDAR_DCN_COORD_BATCH 1  // channels whose loads dcn_col2im_coord_kernel issues together (1 = one channel at a time)
+#endif
 typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));
 
 struct PairFoot {
@@ -373,7 +376,36 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(
     const float h_b0 = e0(hw * bl, q.lw * br), h_b1 = e1(hw * bl, q.lw * br);
     const float w_t0 = e0(-hh * tl, hh * tr), w_t1 = e1(-hh * tl, hh * tr);
     const float w_b0 = e0(-q.lh * bl, q.lh * br), w_b1 = e1(-q.lh * bl, q.lh * br);
-    for (int c = 0; c < g.C; ++c) {
+    int c = 0;
+#if VIDAR_DCN_COORD_BATCH > 1
+    // staged (tools/staged_variants.sh): the loop below keeps 3 loads in flight per thread and waits for them 256
+    // times in a row (the compiler does not cluster the loads of an unrolled body by itself); here the loads of
+    // kCB channels are issued together, the sums are still taken in channel order
+    constexpr int kCB = VIDAR_DCN_COORD_BATCH;
+    const unsigned top_b = (unsigned)top * 4u, bot_b = (unsigned)bot * 4u, p_b = (unsigned)p * 4u;   // plane < 2^30 B
+    const size_t plane_b = (size_t)g.H * g.W * 4, col_b = (size_t)K * P * 4;
+    for (; c + kCB <= g.C; c += kCB) {
+      // wave-uniform bases + 32-bit lane offsets: scalar-base addressing, no 64-bit address pair per load
+      const char* im0 = reinterpret_cast<const char*>(x) + ((size_t)n * g.C + c) * plane_b;
+      const char* gc0 = reinterpret_cast<const char*>(grad_cols) + (((size_t)n * g.C + c) * K + t) * (size_t)P * 4;
+      pair_t a[kCB], b[kCB];
+      float gc[kCB];
+#pragma unroll
+      for (int u = 0; u < kCB; ++u) {
+        gc[u] = *reinterpret_cast<const float*>(gc0 + u * col_b + p_b);
+        a[u] = *reinterpret_cast<const pair_t*>(im0 + u * plane_b + top_b);
+        b[u] = *reinterpret_cast<const pair_t*>(im0 + u * plane_b + bot_b);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < kCB; ++u) {
+        gm += gc[u] * (m_t0 * a[u].x + m_t1 * a[u].y + m_b0 * b[u].x + m_b1 * b[u].y);
+        gh += gc[u] * (h_t0 * a[u].x + h_t1 * a[u].y + h_b0 * b[u].x + h_b1 * b[u].y);
+        gw += gc[u] * (w_t0 * a[u].x + w_t1 * a[u].y + w_b0 * b[u].x + w_b1 * b[u].y);
+      }
+    }
+#endif
+    for (; c < g.C; ++c) {
       const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
       const float gc = grad_cols[(((size_t)n * g.C + c) * K + t) * P + p];
       const pair_t a = *reinterpret_cast<const pair_t*>(im + top);
