@@ -95,7 +95,8 @@ def test_zero_offsets_equal_plain_convolution():
     torch.testing.assert_close(m(x), ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("shape,res", [((2, 8, 6, 8), True), ((1, 5, 7, 5), True), ((3, 4, 29, 50), False)])
+@pytest.mark.parametrize("shape,res", [((2, 8, 6, 8), True), ((1, 5, 7, 5), True), ((3, 4, 29, 50), False),
+                                       ((2, 3, 58, 100), True), ((1, 2, 116, 200), False)])
 def test_fused_frozen_bn_epilogue(shape, res):
     """FrozenBN(x, residual, relu) == relu(batch_norm_eval(x) + residual), values and gradients."""
     from vidar_amd.plugin.backbones import FrozenBN

@@ -167,6 +167,18 @@ def bench_dcn(which):
                    4 * (3 * x.numel() + gcols.numel() + 2 * off.numel() + 2 * mask.numel()))
 
 
+def bench_affine(which):
+    """Frozen BN + (residual) + ReLU of the backbone (csrc/affine_act.hip) at the stage-3 shapes of the 24 history images."""
+    from vidar_amd.plugin.backbones import FrozenBN
+    for C, res in ((1024, True), (256, False)):
+        bn = FrozenBN(C).cuda()
+        x = torch.randn(24, C, 58, 100, device="cuda")
+        r = torch.randn_like(x) if res else None
+        with torch.no_grad():
+            ms = timeit(lambda: bn(x, residual=r, relu=True))
+        report(f"affine_act_fwd [24,{C},58,100] residual={res}", ms, 4 * x.numel() * (3 if res else 2))
+
+
 def bench_norm(which):
     """LayerNorm(dropout(x) + residual) on a [40000, 256] BEV map: fused HIP kernels vs torch's three ops."""
     import torch.nn as nn

@@ -20,7 +20,7 @@ run() {   # name, hipcc flags, pytest selection, kbench target, grep pattern of 
 
 echo "=================== default build"
 python -m vidar_amd.build > /dev/null 2>&1
-timeout 300 python tools/kbench.py dvr dcn 2>&1 | grep -i "render\|im2col\|col2im" | cut -c1-160
+timeout 300 python tools/kbench.py dvr dcn affine 2>&1 | grep -i "render\|im2col\|col2im\|affine" | cut -c1-160
 
 # dvr family: a sample's density is consumed one commit later (dvr_march.h) -- bit-identical arithmetic, the load gets a
 # whole traversal step to arrive; expect the most at <= 1 wave per SIMD (30 k rays), where nothing else hides it
@@ -32,6 +32,9 @@ run dcn_cp4 "-DVIDAR_DCN_CP=4" "tests/test_dcn_gpu.py" dcn "im2col"
 # per call = 256 x one memory latency); the loads of 4 / 8 channels issued together (74 / 128 VGPRs, 6 / 4 waves)
 run dcn_coord4 "-DVIDAR_DCN_COORD_BATCH=4" "tests/test_dcn_gpu.py" dcn "col2im"
 run dcn_coord8 "-DVIDAR_DCN_COORD_BATCH=8" "tests/test_dcn_gpu.py" dcn "col2im"
+# frozen BN + residual + ReLU: 2 / 4 float4 per thread with all loads issued first (5.5 TB/s today, 6.3 achievable)
+run aa_ilp2 "-DVIDAR_AA_ILP=2" "tests/test_dcn_gpu.py" affine "affine"
+run aa_ilp4 "-DVIDAR_AA_ILP=4" "tests/test_dcn_gpu.py" affine "affine"
 
 python -m vidar_amd.build > /dev/null 2>&1
 echo "default build restored"
