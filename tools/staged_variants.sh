@@ -32,6 +32,7 @@ run dcn_cp4 "-DVIDAR_DCN_CP=4" "tests/test_dcn_gpu.py" dcn "im2col"
 # per call = 256 x one memory latency); the loads of 4 / 8 channels issued together (74 / 128 VGPRs, 6 / 4 waves)
 run dcn_coord4 "-DVIDAR_DCN_COORD_BATCH=4" "tests/test_dcn_gpu.py" dcn "col2im"
 run dcn_coord8 "-DVIDAR_DCN_COORD_BATCH=8" "tests/test_dcn_gpu.py" dcn "col2im"
+run dcn_segscan "-DVIDAR_DCN_SEGMENTED_SCAN=1" "tests/test_dcn_gpu.py" dcn "col2im"
 # frozen BN + residual + ReLU: 2 / 4 float4 per thread with all loads issued first (5.5 TB/s today, 6.3 achievable)
 run aa_ilp2 "-DVIDAR_AA_ILP=2" "tests/test_dcn_gpu.py" affine "affine"
 run aa_ilp4 "-DVIDAR_AA_ILP=4" "tests/test_dcn_gpu.py" affine "affine"

@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 #define VIDAR_DCN_CP 16          // channels per thread; 8 needs 52 instead of 85 VGPRs and no scalar spills (tools/staged_variants.sh)
 #endif
 constexpr int kCP = VIDAR_DCN_CP;
+#ifndef VIDAR_DCN_SEGMENTED_SCAN
+#define VIDAR_DCN_SEGMENTED_SCAN 0  // col2im reverse map: one scan workgroup per (image, tap) list instead of per image
+#endif
 #ifndef VIDAR_DCN_COORD_BATCH
 #define VIDAR_DCN_COORD_BATCH 1  // channels whose loads dcn_col2im_coord_kernel issues together (1 = one channel at a time)
 #endif
@@ -487,7 +490,13 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
     if (e != hipSuccess) return (int)e;
     const dim3 rgrid((P + 255) / 256, K, N);
     hipLaunchKernelGGL(dcn_revmap_kernel<false>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
+#if VIDAR_DCN_SEGMENTED_SCAN
+    // staged (tools/staged_variants.sh): a (image, tap) list never holds more than 4 P entries, so every list can own
+    // a fixed slice of `rec` and be scanned by its own workgroup -- N K workgroups instead of N (0.1 ms per call on 6 CUs)
+    hipLaunchKernelGGL(dcn_revmap_scan_kernel, dim3(N * K), dim3(1024), 0, s, cursor, first, HW, P * 4);
+#else
     hipLaunchKernelGGL(dcn_revmap_scan_kernel, dim3(N), dim3(1024), 0, s, cursor, first, K * HW, K * P * 4);
+#endif
     hipLaunchKernelGGL(dcn_revmap_kernel<true>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
     hipLaunchKernelGGL(dcn_col2im_gather_kernel, dim3((HW + 255) / 256, (C + kGC - 1) / kGC, N), dim3(256), 0, s,
                        grad_cols, first, cursor, rec, grad_x, g);
