@@ -1,0 +1,14 @@
+#!/bin/bash
+# The measurements that were prepared without a GPU and are waiting for one:
+#     gpurun --timeout 1500 -- 'bash tools/first_gpu_call.sh'
+# 1. every staged compile-time variant: parity tests, then kernel timing next to the default build
+# 2. HBM traffic counters of the MSDA kernels on COHERENT reference points (the committed numbers are for random ones)
+# Everything lands in gpurun_out/first_call/ ; copy what is kept into profiles/.
+set -u
+cd "$(dirname "$0")/.."
+out=gpurun_out/first_call
+mkdir -p $out
+bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
+tail -60 $out/staged_variants.log
+bash tools/pmc_pass.sh $out/pmc_msda_coherent "FETCH_SIZE WRITE_SIZE TCC_HIT_sum,TCC_MISS_sum" python tools/kbench.py msda_coherent > $out/pmc_msda_coherent.log 2>&1
+ls $out/pmc_msda_coherent 2>/dev/null && head -20 $out/pmc_msda_coherent/*.csv
