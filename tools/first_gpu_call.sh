@@ -10,5 +10,5 @@ out=gpurun_out/first_call
 mkdir -p $out
 bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
 tail -60 $out/staged_variants.log
-bash tools/pmc_pass.sh $out/pmc_msda_coherent "FETCH_SIZE WRITE_SIZE TCC_HIT_sum,TCC_MISS_sum" python tools/kbench.py msda_coherent > $out/pmc_msda_coherent.log 2>&1
+bash tools/pmc_pass.sh $out/pmc_msda_coherent "FETCH_SIZE WRITE_SIZE TCC_HIT,TCC_MISS" python tools/kbench.py msda_coherent > $out/pmc_msda_coherent.log 2>&1
 ls $out/pmc_msda_coherent 2>/dev/null && head -20 $out/pmc_msda_coherent/*.csv
