@@ -20,7 +20,7 @@ run() {   # name, hipcc flags, pytest selection, kbench target, grep pattern of 
 
 echo "=================== default build"
 python -m vidar_amd.build > /dev/null 2>&1
-timeout 300 python tools/kbench.py dvr dcn affine 2>&1 | grep -i "render\|im2col\|col2im\|affine" | cut -c1-160
+timeout 300 python tools/kbench.py dvr dcn affine ray 2>&1 | grep -i "render\|im2col\|col2im\|affine\|ray_" | cut -c1-160
 
 # dvr family: a sample's density is consumed one commit later (dvr_march.h) -- bit-identical arithmetic, the load gets a
 # whole traversal step to arrive; expect the most at <= 1 wave per SIMD (30 k rays), where nothing else hides it
@@ -33,6 +33,9 @@ run dcn_cp4 "-DVIDAR_DCN_CP=4" "tests/test_dcn_gpu.py" dcn "im2col"
 run dcn_coord4 "-DVIDAR_DCN_COORD_BATCH=4" "tests/test_dcn_gpu.py" dcn "col2im"
 run dcn_coord8 "-DVIDAR_DCN_COORD_BATCH=8" "tests/test_dcn_gpu.py" dcn "col2im"
 run dcn_segscan "-DVIDAR_DCN_SEGMENTED_SCAN=1" "tests/test_dcn_gpu.py" dcn "col2im"
+# ray kernels of the head: leave the 512-waypoint loop after the run of live waypoints (60-140 of 512: on average 3.9 of
+# the 16 backward passes and 2.6 of the 8 forward passes are executed, tests/test_ray_early_exit_cpu.py)
+run ray_early "-DVIDAR_RAY_EARLY_EXIT=1" "tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py tests/test_reference_golden_gpu.py" ray "ray_"
 # frozen BN + residual + ReLU: 2 / 4 float4 per thread with all loads issued first (5.5 TB/s today, 6.3 achievable)
 run aa_ilp2 "-DVIDAR_AA_ILP=2" "tests/test_dcn_gpu.py" affine "affine"
 run aa_ilp4 "-DVIDAR_AA_ILP=4" "tests/test_dcn_gpu.py" affine "affine"

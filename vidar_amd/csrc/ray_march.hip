@@ -131,10 +131,44 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr float kNegInf = -__builtin_inff();
 
+// Staged (tools/staged_variants.sh), default off.  The waypoints of a ray that lie inside the open volume are ONE run
+// of consecutive k (a line meets a convex box in a segment), and with the recipe's geometry that run is 60-140 of the
+// 512 waypoints: most passes of the kernels below only compute footprints that are then masked.  With
+// VIDAR_RAY_EARLY_EXIT a wave stops after the first pass without a live waypoint that follows a pass with one (passes
+// are blocks of consecutive k, so no later waypoint can be live); a masked waypoint contributes -inf / nothing, so
+// every result is unchanged.  tests/test_ray_early_exit_cpu.py checks the single-run property in the kernels' fp32
+// arithmetic.
+#ifndef VIDAR_RAY_EARLY_EXIT
+#define VIDAR_RAY_EARLY_EXIT 0
+#endif
+struct RunTracker {
+  bool seen = false;
+  // true when the pass just finished (wave-uniform `live` = some lane had an unmasked waypoint) ends the run
+  __device__ __forceinline__ bool done_after(bool live) {
+    if (live) { seen = true; return false; }
+    return seen;
+  }
+};
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
 // logits of the K waypoints owned by this lane
 __device__ __forceinline__ void lane_logits(const float* __restrict__ vol, const Ray& r,
                                             const VolDims& v, float step, int lane,
                                             float (&f)[kPerLane]) {
+#if VIDAR_RAY_EARLY_EXIT
+  RunTracker run;
+  bool done = false;
+#pragma unroll
+  for (int j = 0; j < kPerLane; ++j) {
+    f[j] = kNegInf;
+    if (done) continue;                                  // wave-uniform
+    float sx, sy, sz;
+    waypoint(r, lane + j * kWave, step, sx, sy, sz);
+    const Tri t = make_tri(sx, sy, sz, v);
+    if (!t.masked) f[j] = tri_load(vol, t);
+    done = run.done_after(wave_any(!t.masked));
+  }
+#else
 #pragma unroll
   for (int j = 0; j < kPerLane; ++j) {
     float sx, sy, sz;
@@ -142,6 +176,7 @@ __device__ __forceinline__ void lane_logits(const float* __restrict__ vol, const
     const Tri t = make_tri(sx, sy, sz, v);
     f[j] = t.masked ? kNegInf : tri_load(vol, t);
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -198,11 +233,17 @@ __global__ __launch_bounds__(kThreads) void ray_ce_bwd_kernel(
   const float lse = lse_in[r];
   if (lane == 0) tri_scatter(gvol, t0, g * (expf(tri_load(vol, t0) - lse) - 1.f));
   const int cx = lane & 1;
+#if VIDAR_RAY_EARLY_EXIT
+  RunTracker run;
+#endif
   for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
     float sx, sy, sz;
     waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
     const Tri t = make_tri(sx, sy, sz, v);
     if (!t.masked) tri_scatter_x(gvol, t, g * expf(tri_load(vol, t) - lse), cx);
+#if VIDAR_RAY_EARLY_EXIT
+    if (run.done_after(wave_any(!t.masked))) break;
+#endif
   }
 }
 
@@ -280,6 +321,20 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
   float* gvol = grad_sigma + slice;
   const float pd = aux[(size_t)r * 3 + 0], pn = aux[(size_t)r * 3 + 1], lse = aux[(size_t)r * 3 + 2];
   const int cx = lane & 1;
+#if VIDAR_RAY_EARLY_EXIT
+  RunTracker run;
+  for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
+    float sx, sy, sz;
+    waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
+    const Tri t = make_tri(sx, sy, sz, v);
+    if (!t.masked) {
+      const float p = expf(tri_load(vol, t) - lse);
+      const float ind = dist_to(ray, sx, sy, sz) > pd ? 1.f : 0.f;
+      tri_scatter_x(gvol, t, g * pd * p * (ind - pn), cx);
+    }
+    if (run.done_after(wave_any(!t.masked))) break;
+  }
+#else
   for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
     float sx, sy, sz;
     waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
@@ -289,6 +344,7 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
     const float ind = dist_to(ray, sx, sy, sz) > pd ? 1.f : 0.f;
     tri_scatter_x(gvol, t, g * pd * p * (ind - pn), cx);
   }
+#endif
 }
 
 // test-time decode: exact zeros are masked to -inf (:728), arg-max waypoint -> distance
