@@ -3,6 +3,7 @@
 #     gpurun --timeout 1500 -- 'bash tools/first_gpu_call.sh'
 # 1. every staged compile-time variant: parity tests, then kernel timing next to the default build
 # 2. HBM traffic counters of the MSDA kernels on COHERENT reference points (the committed numbers are for random ones)
+# 3. whole-step A/B of the optimizer implementation
 # Everything lands in gpurun_out/first_call/ ; copy what is kept into profiles/.
 set -u
 cd "$(dirname "$0")/.."
@@ -10,5 +11,10 @@ out=gpurun_out/first_call
 mkdir -p $out
 bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
 tail -60 $out/staged_variants.log
+# 3. optimizer: foreach AdamW (default) vs torch's fused AdamW
+for f in 0 1; do
+  VIDAR_FUSED_ADAMW=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \
+      2> /dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('fused_adamw=$f', round(d['ms_per_step'], 2), 'ms/step')"
+done | tee $out/fused_adamw_ab.log
 bash tools/pmc_pass.sh $out/pmc_msda_coherent "FETCH_SIZE WRITE_SIZE TCC_HIT,TCC_MISS" python tools/kbench.py msda_coherent > $out/pmc_msda_coherent.log 2>&1
 ls $out/pmc_msda_coherent 2>/dev/null && head -20 $out/pmc_msda_coherent/*.csv
