@@ -515,7 +515,7 @@ def main():
                "warmup": args.extra_warmup, "n_gpus": world, "global_batch": world * xspg,
                "cameras": r["cfg"]["num_cams"], "img_hw": list(r["cfg"]["img_hw"])}
         if r["ops"]:
-            dn, dv = max(((k, v) for k, v in r["ops"].items() if not k.startswith(("dcn_", "affine_act"))),
+            dn, dv = max(((k, v) for k, v in r["ops"].items() if not k.startswith(("dcn_", "affine_act", "stem_"))),
                          key=lambda kv: kv[1]["total_ms"])
             ach = dv["bytes_per_call"] / (dv["avg_ms"] * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "kernel": dn, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -533,7 +533,7 @@ def main():
                       f"total/step {v['total_ms'] / args.steps:8.2f} ms  alg {gb:8.1f} GB/s", file=sys.stderr)
         # `roofline`: the dominant kernel of the SURVEY 8(a) hot path (MSDA / latent render / ray march / chamfer);
         # the backbone's kernels (row f-1: dcn_*, affine_act_*) compete in `roofline_step_dominant`
-        hot = {k: v for k, v in ops.items() if not k.startswith(("dcn_", "affine_act"))} or ops
+        hot = {k: v for k, v in ops.items() if not k.startswith(("dcn_", "affine_act", "stem_"))} or ops
         dom_name, dom = max(hot.items(), key=lambda kv: kv[1]["total_ms"])
         achieved = dom["bytes_per_call"] / (dom["avg_ms"] * 1e-3) / 1e9
         all_name, all_dom = max(ops.items(), key=lambda kv: kv[1]["total_ms"])

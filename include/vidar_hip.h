@@ -325,6 +325,13 @@ size_t vidar_dcn_col2im_workspace_bytes(int N, int H, int W, int Ho, int Wo, int
 int vidar_affine_act_fwd_f32(const float* x, const float* scale, const float* shift,
                              const float* residual, float* y, int N, int C, int HW, int relu,
                              void* stream);
+/* Stem of the backbone in one pass: y[N,C,Ho,Wo] = max_pool2d(relu(x*scale[c] + shift[c]), 3, stride 2, pad 1) with
+ * Ho = (H-1)/2 + 1, Wo = W/2 -- mmdet ResNet.forward's conv1 -> norm1 -> relu -> maxpool with the frozen BN of the
+ * ViDAR configs (vidar_1_8_nusc_1future.py:86-95, frozen_stages=1: forward only).  Bit-identical to
+ * vidar_affine_act_fwd_f32(relu=1) followed by the pooling.  VIDAR_ERR_BAD_ARG unless W % 4 == 0, x 16-byte and
+ * y 8-byte aligned, N*C <= 65535 (the caller then takes the two-kernel path). */
+int vidar_stem_bn_relu_pool_f32(const float* x, const float* scale, const float* shift, float* y, int N, int C,
+                                int H, int W, void* stream);
 int vidar_affine_act_bwd_f32(const float* grad_y, const float* y, const float* scale, float* grad_x,
                              float* grad_residual, int N, int C, int HW, int relu, void* stream);
 

@@ -1,5 +1,7 @@
 """GPU parity: DCNv2 (HIP im2col/col2im + GEMM) vs the grid_sample oracle, forward and all five
 gradients; tolerance 1e-4 (fp32 sums over C*9 products).  Oracle is 'parity unpinned' (mmcv)."""
+import os
+
 import pytest
 import torch
 
@@ -136,3 +138,22 @@ def test_conv1x1_as_batched_gemm_equals_conv2d(stride, bias):
     for u, v in zip(a, b):
         torch.testing.assert_close(u, v, rtol=1e-4, atol=1e-4 * max(1.0, float(v.abs().max())))
     assert sorted(m.state_dict()) == (["bias", "weight"] if bias else ["weight"]) and m.weight.shape == (40, 24, 1, 1)
+
+
+@pytest.mark.skipif(os.environ.get("VIDAR_STAGED") != "1",
+                    reason="staged kernel (written without a GPU): tools/first_gpu_call.sh runs it with VIDAR_STAGED=1")
+@pytest.mark.parametrize("shape", [(2, 3, 8, 8), (1, 4, 7, 12), (1, 2, 1, 4), (3, 64, 58, 100), (2, 64, 464, 800)])
+def test_fused_stem_pool_matches_two_kernel_path(shape):
+    """vidar_stem_bn_relu_pool_f32 == max_pool2d(FrozenBN(x, relu=True), 3, 2, 1), bit for bit"""
+    from vidar_amd.plugin.backbones import FrozenBN, stem_bn_relu_pool
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    bn = FrozenBN(shape[1]).cuda()
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+    x = torch.randn(*shape, device="cuda")
+    with torch.no_grad():
+        ref = F.max_pool2d(bn(x, relu=True), 3, stride=2, padding=1)
+        out = stem_bn_relu_pool(x, bn)
+    assert out is not None and out.shape == ref.shape
+    assert torch.equal(out, ref)
+    assert stem_bn_relu_pool(x.requires_grad_(), bn) is None           # gradients needed -> the caller's two-kernel path

@@ -11,6 +11,12 @@ out=gpurun_out/first_call
 mkdir -p $out
 bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
 tail -60 $out/staged_variants.log
+# 2b. the staged stem kernel (BN + ReLU + max-pool in one pass): its bit-exactness test, then the whole-step A/B
+VIDAR_STAGED=1 timeout 300 python -m pytest tests/test_dcn_gpu.py -q -m gpu -k fused_stem 2>&1 | tail -2 | tee $out/fused_stem_test.log
+for f in 0 1; do
+  VIDAR_FUSED_STEM=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \
+      2> /dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('fused_stem=$f', round(d['ms_per_step'], 2), 'ms/step')"
+done | tee $out/fused_stem_ab.log
 # 3. optimizer: foreach AdamW (default) vs torch's fused AdamW
 for f in 0 1; do
   VIDAR_FUSED_ADAMW=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \

@@ -118,6 +118,42 @@ inline dim3 aa_grid_fwd(int N, int C, int HW) {
   if (bx > 64) bx = 64;
   return dim3(bx, N * C);
 }
+// Stem of the ResNet (conv1 -> frozen BN -> ReLU -> 3x3 / stride 2 / pad 1 max-pool; the stem is frozen in every
+// ViDAR config, `frozen_stages=1`, so it is forward only): BN + ReLU + pool in ONE pass over the conv1 output instead
+// of affine_act (read + write of the full-resolution map) followed by torch's pooling kernel (1.75 TB/s).  A thread
+// produces a 2 x 2 block of outputs from 5 rows x (one float4 + the column left of it); the affine is the same fused
+// multiply-add affine_act_fwd_kernel compiles to, and max / ReLU commute, so the result is bit-identical to the
+// two-kernel path.  Needs W % 4 == 0.   grid: (ceil(W/4 / 64), ceil(ceil(Ho/2) / 4), N*C), 256 threads.
+__global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ y,
+                                                        int C, int H, int W, int Ho, int Wo) {
+  const int plane = blockIdx.z;
+  const float s = scale[plane % C], b = shift[plane % C];
+  const int t = blockIdx.x * 64 + (threadIdx.x & 63);          // output columns 2t, 2t+1 <- input columns 4t-1 .. 4t+3
+  const int r = blockIdx.y * 4 + (threadIdx.x >> 6);           // output rows 2r, 2r+1    <- input rows 4r-1 .. 4r+3
+  if (t >= (W >> 2) || 2 * r >= Ho) return;
+  const float* in = x + (size_t)plane * H * W;
+  float* out = y + (size_t)plane * Ho * Wo;
+  const float ninf = -__builtin_inff();
+  float m0a = ninf, m0b = ninf, m1a = ninf, m1b = ninf;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int row = 4 * r - 1 + i;
+    if (row < 0 || row >= H) continue;
+    const float* p = in + (size_t)row * W + 4 * t;
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    float l = ninf;
+    if (t > 0) l = fmaxf(__builtin_fmaf(p[-1], s, b), 0.f);
+    const float vx = fmaxf(__builtin_fmaf(v.x, s, b), 0.f), vy = fmaxf(__builtin_fmaf(v.y, s, b), 0.f);
+    const float vz = fmaxf(__builtin_fmaf(v.z, s, b), 0.f), vw = fmaxf(__builtin_fmaf(v.w, s, b), 0.f);
+    const float a = fmaxf(fmaxf(l, vx), vy), c2 = fmaxf(fmaxf(vy, vz), vw);
+    if (i <= 2) { m0a = fmaxf(m0a, a); m0b = fmaxf(m0b, c2); }
+    if (i >= 2) { m1a = fmaxf(m1a, a); m1b = fmaxf(m1b, c2); }
+  }
+  *reinterpret_cast<float2*>(out + (size_t)(2 * r) * Wo + 2 * t) = make_float2(m0a, m0b);
+  if (2 * r + 1 < Ho) *reinterpret_cast<float2*>(out + (size_t)(2 * r + 1) * Wo + 2 * t) = make_float2(m1a, m1b);
+}
+
 inline dim3 aa_grid(int N, int C, int HW) {
   int bx = (HW / 4 + 255) / 256;
   if (bx < 1) bx = 1;
@@ -143,6 +179,18 @@ int vidar_affine_act_fwd_f32(const float* x, const float* scale, const float* sh
   else
     hipLaunchKernelGGL(affine_act_fwd_kernel<false>, aa_grid(N, C, HW * 4), dim3(256), 0,
                        (hipStream_t)stream, x, scale, shift, residual, y, C, HW, relu);
+  return vidar_last_error();
+}
+
+int vidar_stem_bn_relu_pool_f32(const float* x, const float* scale, const float* shift, float* y, int N, int C,
+                                int H, int W, void* stream) {
+  VIDAR_ENTER();
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0 || (W & 3) || !aligned16(x) || ((uintptr_t)y & 7)) return VIDAR_ERR_BAD_ARG;
+  if ((int64_t)N * C > 65535) return VIDAR_ERR_BAD_ARG;          // grid.z
+  if (N == 0) return 0;
+  const int Ho = (H - 1) / 2 + 1, Wo = W / 2;
+  const dim3 grid(((W >> 2) + 63) / 64, ((Ho + 1) / 2 + 3) / 4, N * C);
+  hipLaunchKernelGGL(stem_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, C, H, W, Ho, Wo);
   return vidar_last_error();
 }
 

@@ -167,6 +167,24 @@ class FrozenBN(nn.BatchNorm2d):
         return _AffineAct.apply(x, scale, shift, residual, relu)
 
 
+def stem_bn_relu_pool(x, bn):
+    """max_pool2d(relu(bn(x)), 3, 2, 1) of the frozen stem in one pass (vidar_stem_bn_relu_pool_f32), or None when
+    the fused kernel does not apply (gradients needed, trainable BN, CPU tensor, W % 4 != 0): the caller then takes
+    the two-kernel path.  Staged: only reached with VIDAR_FUSED_STEM=1."""
+    if not x.is_cuda or bn.weight.requires_grad or (torch.is_grad_enabled() and x.requires_grad):
+        return None
+    x = x.float().contiguous()
+    N, C, H, W = x.shape
+    if W % 4 or N * C > 65535:
+        return None
+    scale, shift = bn._scale_shift()
+    y = torch.empty((N, C, (H - 1) // 2 + 1, W // 2), device=x.device, dtype=torch.float32)
+    with TIMER.span("stem_bn_relu_pool", 4 * (x.numel() + y.numel())):
+        check(lib().vidar_stem_bn_relu_pool_f32(ptr(x), ptr(scale), ptr(shift), ptr(y), N, C, H, W, stream_of(x)),
+              "stem_bn_relu_pool")
+    return y
+
+
 class Conv1x1(nn.Conv2d):
     """1x1 convolution as a batched GEMM  out[n] = W [Cout, Cin] x[n] [Cin, H*W]  on NCHW tensors.  Same parameter
     names / shapes as nn.Conv2d (`weight` [Cout, Cin, 1, 1]); two thirds of ResNet101's convolutions are 1x1, and as
@@ -253,7 +271,9 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        x = F.max_pool2d(self.bn1(self.conv1(x), relu=True), 3, stride=2, padding=1)
+        x = self.conv1(x)
+        y = stem_bn_relu_pool(x, self.bn1) if os.environ.get("VIDAR_FUSED_STEM") == "1" else None
+        x = y if y is not None else F.max_pool2d(self.bn1(x, relu=True), 3, stride=2, padding=1)
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)
