@@ -1,5 +1,6 @@
 #!/bin/bash
 # The measurements that were prepared without a GPU and are waiting for one:
+#     bash tools/staged_variants.sh prebuild        # here, on the CPU box: the variant libraries travel with the snapshot
 #     gpurun --timeout 1500 -- 'bash tools/first_gpu_call.sh'
 # 1. every staged compile-time variant: parity tests, then kernel timing next to the default build
 # 2. HBM traffic counters of the MSDA kernels on COHERENT reference points (the committed numbers are for random ones)

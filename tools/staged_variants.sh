@@ -1,44 +1,70 @@
 #!/bin/bash
 # Compile-time variants that are STAGED in the source -- written and checked without a GPU (logic on the host where the
-# code is host-compilable, device code of the default build proven unchanged by disassembly), default off -- and wait
-# for one GPU run each: parity tests first, then the kernel timing next to the default build.  Run on a GPU box:
-#     tools/staged_variants.sh            # every variant
-#     tools/staged_variants.sh dvr_pipe   # one
+# code is host-compilable, device code of the default build proven unchanged by `tools/devcode.py head-diff`), default
+# off -- and wait for one GPU run each: parity tests first, then the kernel timing next to the default build.
+#     tools/staged_variants.sh prebuild     # on the CPU box: one libvidar_hip.so per variant into vidar_amd/_staged/
+#                                           # (git-ignored, travels with gpurun: no compile time on the GPU box)
+#     tools/staged_variants.sh              # on a GPU box: every variant   (tools/staged_variants.sh dvr_pipe: one)
 # The default build is restored at the end.  A variant is promoted by making its macro the default in the source.
 set -u
 cd "$(dirname "$0")/.."
 want="${1:-all}"
+staged=vidar_amd/_staged
+lib=vidar_amd/libvidar_hip.so
 
-run() {   # name, hipcc flags, pytest selection, kbench target, grep pattern of the kbench lines
-  local name="$1" flags="$2" tests="$3" kb="$4" pat="$5"
-  [ "$want" = all ] || [ "$want" = "$name" ] || return 0
-  echo "=================== $name   ($flags)"
-  VIDAR_EXTRA_HIPCC_FLAGS="$flags" python -m vidar_amd.build > /dev/null 2>&1 || { echo "build failed"; return 0; }
-  timeout 900 python -m pytest $tests -x -q -m gpu 2>&1 | tail -2
-  timeout 300 python tools/kbench.py $kb 2>&1 | grep -i "$pat" | cut -c1-160
+# name | source file the flags apply to | hipcc flags | pytest selection | kbench target | grep pattern of the kbench lines
+variants() { cat <<'TABLE'
+dvr_pipe|dvr_family.hip|-DVIDAR_DVR_PIPELINED_SIGMA|tests/test_dvr_gpu.py tests/test_fullsize_parity_gpu.py tests/test_dropin_gpu.py|dvr|render
+dcn_cp8|dcn.hip|-DVIDAR_DCN_CP=8|tests/test_dcn_gpu.py|dcn|im2col
+dcn_cp4|dcn.hip|-DVIDAR_DCN_CP=4|tests/test_dcn_gpu.py|dcn|im2col
+dcn_coord4|dcn.hip|-DVIDAR_DCN_COORD_BATCH=4|tests/test_dcn_gpu.py|dcn|col2im
+dcn_coord8|dcn.hip|-DVIDAR_DCN_COORD_BATCH=8|tests/test_dcn_gpu.py|dcn|col2im
+dcn_segscan|dcn.hip|-DVIDAR_DCN_SEGMENTED_SCAN=1|tests/test_dcn_gpu.py|dcn|col2im
+ray_early|ray_march.hip|-DVIDAR_RAY_EARLY_EXIT=1|tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py tests/test_reference_golden_gpu.py|ray|ray_
+aa_ilp2|affine_act.hip|-DVIDAR_AA_ILP=2|tests/test_dcn_gpu.py|affine|affine
+aa_ilp4|affine_act.hip|-DVIDAR_AA_ILP=4|tests/test_dcn_gpu.py|affine|affine
+TABLE
+}
+# what each one is:
+#  dvr_pipe    a sample's density is consumed one commit later (dvr_march.h): bit-identical arithmetic, the load gets a
+#              whole traversal step to arrive; expect the most at <= 1 wave per SIMD (30 k rays)
+#  dcn_cp8/4   im2col channels per thread: 16 = 85 VGPRs, 27 scalar registers parked in VGPR lanes, 5 waves; 8 = 52 / 0 / 8
+#  dcn_coord*  offset / mask gradient: the loads of 4 / 8 channels issued together (today: 3 loads, wait, 256 times)
+#  dcn_segscan col2im reverse map: one scan workgroup per (image, tap) list instead of per image
+#  ray_early   leave the 512-waypoint loops after the run of live waypoints (on average 3.9 of 16 passes are needed)
+#  aa_ilp*     frozen BN + residual + ReLU: 2 / 4 float4 per thread, all loads first
+
+build_variant() {   # file, flags
+  VIDAR_EXTRA_HIPCC_ONLY="$1" VIDAR_EXTRA_HIPCC_FLAGS="$2" python -m vidar_amd.build > /dev/null 2>&1
+}
+
+if [ "$want" = prebuild ]; then
+  mkdir -p $staged
+  python -m vidar_amd.build > /dev/null 2>&1 && cp $lib $staged/default.so
+  variants | while IFS='|' read -r name file flags tests kb pat; do
+    build_variant "$file" "$flags" && cp $lib $staged/$name.so && echo "prebuilt $name" || echo "build failed: $name"
+  done
+  python -m vidar_amd.build > /dev/null 2>&1
+  cmp -s $lib $staged/default.so || cp $staged/default.so $lib
+  ls -la $staged
+  exit 0
+fi
+
+use() {   # name, file, flags -> installs the variant library
+  if [ -f $staged/$1.so ]; then cp $staged/$1.so $lib; else build_variant "$2" "$3"; fi
 }
 
 echo "=================== default build"
-python -m vidar_amd.build > /dev/null 2>&1
+if [ -f $staged/default.so ]; then cp $staged/default.so $lib; else python -m vidar_amd.build > /dev/null 2>&1; fi
 timeout 300 python tools/kbench.py dvr dcn affine ray 2>&1 | grep -i "render\|im2col\|col2im\|affine\|ray_" | cut -c1-160
 
-# dvr family: a sample's density is consumed one commit later (dvr_march.h) -- bit-identical arithmetic, the load gets a
-# whole traversal step to arrive; expect the most at <= 1 wave per SIMD (30 k rays), where nothing else hides it
-run dvr_pipe "-DVIDAR_DVR_PIPELINED_SIGMA" "tests/test_dvr_gpu.py tests/test_fullsize_parity_gpu.py tests/test_dropin_gpu.py" dvr "render"
-# DCN im2col: 8 channels per thread = 52 VGPRs, no scalar spills, 8 waves per SIMD (16: 85 / 27 / 5)
-run dcn_cp8 "-DVIDAR_DCN_CP=8" "tests/test_dcn_gpu.py" dcn "im2col"
-run dcn_cp4 "-DVIDAR_DCN_CP=4" "tests/test_dcn_gpu.py" dcn "im2col"
-# DCN col2im, offset / mask gradient: the channel loop keeps 3 loads in flight and waits 256 times in a row (0.144 ms
-# per call = 256 x one memory latency); the loads of 4 / 8 channels issued together (74 / 128 VGPRs, 6 / 4 waves)
-run dcn_coord4 "-DVIDAR_DCN_COORD_BATCH=4" "tests/test_dcn_gpu.py" dcn "col2im"
-run dcn_coord8 "-DVIDAR_DCN_COORD_BATCH=8" "tests/test_dcn_gpu.py" dcn "col2im"
-run dcn_segscan "-DVIDAR_DCN_SEGMENTED_SCAN=1" "tests/test_dcn_gpu.py" dcn "col2im"
-# ray kernels of the head: leave the 512-waypoint loop after the run of live waypoints (60-140 of 512: on average 3.9 of
-# the 16 backward passes and 2.6 of the 8 forward passes are executed, tests/test_ray_early_exit_cpu.py)
-run ray_early "-DVIDAR_RAY_EARLY_EXIT=1" "tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py tests/test_reference_golden_gpu.py" ray "ray_"
-# frozen BN + residual + ReLU: 2 / 4 float4 per thread with all loads issued first (5.5 TB/s today, 6.3 achievable)
-run aa_ilp2 "-DVIDAR_AA_ILP=2" "tests/test_dcn_gpu.py" affine "affine"
-run aa_ilp4 "-DVIDAR_AA_ILP=4" "tests/test_dcn_gpu.py" affine "affine"
+variants | while IFS='|' read -r name file flags tests kb pat; do
+  [ "$want" = all ] || [ "$want" = "$name" ] || continue
+  echo "=================== $name   ($flags)"
+  use "$name" "$file" "$flags" || { echo "build failed"; continue; }
+  VIDAR_STAGED=1 timeout 900 python -m pytest $tests -x -q -m gpu 2>&1 | tail -2
+  timeout 300 python tools/kbench.py $kb 2>&1 | grep -i "$pat" | cut -c1-160
+done
 
-python -m vidar_amd.build > /dev/null 2>&1
+if [ -f $staged/default.so ]; then cp $staged/default.so $lib; else python -m vidar_amd.build > /dev/null 2>&1; fi
 echo "default build restored"

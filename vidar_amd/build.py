@@ -49,7 +49,12 @@ def _stamp(src: Path, flags: list[str]) -> str:
 
 
 def _compile(src: Path, verbose: bool) -> Path:
-    flags = COMMON + PER_FILE.get(src.name, []) + os.environ.get("VIDAR_EXTRA_HIPCC_FLAGS", "").split()
+    # VIDAR_EXTRA_HIPCC_FLAGS: extra flags (the -D switches of the tuning sweeps / staged variants) for every source,
+    # or only for the sources named in VIDAR_EXTRA_HIPCC_ONLY (comma separated file names) -- the others keep their
+    # objects, so a one-file variant rebuilds in seconds
+    only = [n for n in os.environ.get("VIDAR_EXTRA_HIPCC_ONLY", "").split(",") if n]
+    extra = os.environ.get("VIDAR_EXTRA_HIPCC_FLAGS", "").split() if (not only or src.name in only) else []
+    flags = COMMON + PER_FILE.get(src.name, []) + extra
     obj = OBJ / (src.stem + ".o")
     stamp = OBJ / (src.stem + ".stamp")
     want = _stamp(src, flags)
