@@ -7,7 +7,7 @@ set -u
 cd "$(dirname "$0")/.."
 for v in "3 1024" "3 512" "3 2048" "2 1024"; do
   set -- $v
-  VIDAR_EXTRA_HIPCC_FLAGS="-DVIDAR_MSDA_TILE_SHIFT=$1 -DVIDAR_MSDA_CHUNK=$2" python -m vidar_amd.build > /dev/null 2>&1 || { echo "build failed: $v"; continue; }
+  VIDAR_EXTRA_HIPCC_ONLY=msda.hip VIDAR_EXTRA_HIPCC_FLAGS="-DVIDAR_MSDA_TILE_SHIFT=$1 -DVIDAR_MSDA_CHUNK=$2" python -m vidar_amd.build > /dev/null 2>&1 || { echo "build failed: $v"; continue; }
   echo "== tile_shift=$1 chunk=$2"
   timeout 200 python tools/kbench.py msda 2>&1 | grep "binned=True" | cut -c1-120
 done
