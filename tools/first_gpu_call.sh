@@ -18,6 +18,13 @@ for f in 0 1; do
   VIDAR_FUSED_STEM=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \
       2> /dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('fused_stem=$f', round(d['ms_per_step'], 2), 'ms/step')"
 done | tee $out/fused_stem_ab.log
+# 2c. padded SpatialCrossAttention slots with NaN anchors (skipped by the MSDA kernels): step parity, then the A/B
+VIDAR_SCA_PAD_NAN=1 timeout 600 python -m pytest tests/test_step_gpu.py tests/test_reference_golden_gpu.py -x -q -m gpu 2>&1 | tail -2 | tee $out/sca_pad_nan_test.log
+for f in 0 1; do
+  VIDAR_SCA_PAD_NAN=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" --op-table \
+      2> $out/sca_pad_nan_$f.optable | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('sca_pad_nan=$f', round(d['ms_per_step'], 2), 'ms/step')"
+  grep "msda_" $out/sca_pad_nan_$f.optable
+done | tee $out/sca_pad_nan_ab.log
 # 3. optimizer: foreach AdamW (default) vs torch's fused AdamW
 for f in 0 1; do
   VIDAR_FUSED_ADAMW=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \
