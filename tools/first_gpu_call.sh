@@ -20,11 +20,15 @@ for f in 0 1; do
 done | tee $out/fused_stem_ab.log
 # 2c. padded SpatialCrossAttention slots with NaN anchors (skipped by the MSDA kernels): step parity, then the A/B
 VIDAR_SCA_PAD_NAN=1 timeout 600 python -m pytest tests/test_step_gpu.py tests/test_reference_golden_gpu.py -x -q -m gpu 2>&1 | tail -2 | tee $out/sca_pad_nan_test.log
-for f in 0 1; do
-  VIDAR_SCA_PAD_NAN=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" --op-table \
-      2> $out/sca_pad_nan_$f.optable | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('sca_pad_nan=$f', round(d['ms_per_step'], 2), 'ms/step')"
-  grep "msda_" $out/sca_pad_nan_$f.optable
+for v in default msda_skip; do
+  [ -f vidar_amd/_staged/$v.so ] && cp vidar_amd/_staged/$v.so vidar_amd/libvidar_hip.so
+  for f in 0 1; do
+    VIDAR_SCA_PAD_NAN=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" --op-table \
+        2> $out/sca_pad_nan_${v}_$f.optable | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('lib=$v sca_pad_nan=$f', round(d['ms_per_step'], 2), 'ms/step')"
+    grep "msda_" $out/sca_pad_nan_${v}_$f.optable
+  done
 done | tee $out/sca_pad_nan_ab.log
+[ -f vidar_amd/_staged/default.so ] && cp vidar_amd/_staged/default.so vidar_amd/libvidar_hip.so
 # 3. optimizer: foreach AdamW (default) vs torch's fused AdamW
 for f in 0 1; do
   VIDAR_FUSED_ADAMW=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \

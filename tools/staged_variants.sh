@@ -21,6 +21,7 @@ dcn_coord4|dcn.hip|-DVIDAR_DCN_COORD_BATCH=4|tests/test_dcn_gpu.py|dcn|col2im
 dcn_coord8|dcn.hip|-DVIDAR_DCN_COORD_BATCH=8|tests/test_dcn_gpu.py|dcn|col2im
 dcn_segscan|dcn.hip|-DVIDAR_DCN_SEGMENTED_SCAN=1|tests/test_dcn_gpu.py|dcn|col2im
 ray_early|ray_march.hip|-DVIDAR_RAY_EARLY_EXIT=1|tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py tests/test_reference_golden_gpu.py|ray|ray_
+msda_skip|msda.hip|-DVIDAR_MSDA_SKIP_DEAD=1|tests/test_msda_gpu.py tests/test_step_gpu.py|msda|msda
 aa_ilp2|affine_act.hip|-DVIDAR_AA_ILP=2|tests/test_dcn_gpu.py|affine|affine
 aa_ilp4|affine_act.hip|-DVIDAR_AA_ILP=4|tests/test_dcn_gpu.py|affine|affine
 TABLE
@@ -32,6 +33,8 @@ TABLE
 #  dcn_coord*  offset / mask gradient: the loads of 4 / 8 channels issued together (today: 3 loads, wait, 256 times)
 #  dcn_segscan col2im reverse map: one scan workgroup per (image, tap) list instead of per image
 #  ray_early   leave the 512-waypoint loops after the run of live waypoints (on average 3.9 of 16 passes are needed)
+#  msda_skip   MSDA forward / grad_loc kernels: an item without a live sample issues no corner loads (pays off together with
+#              VIDAR_SCA_PAD_NAN=1, timed in tools/first_gpu_call.sh; alone it only adds the check: expect +-0)
 #  aa_ilp*     frozen BN + residual + ReLU: 2 / 4 float4 per thread, all loads first
 
 build_variant() {   # file, flags
