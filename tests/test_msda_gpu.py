@@ -244,3 +244,32 @@ def test_one_hot_destination_pixel_many_chunks():
     b = F._msda_backward(value.cuda(), sh.cuda(), lsi, loc.cuda(), w.cuda(), go, binned=False)
     for u, v in zip(a, b):
         torch.testing.assert_close(u, v, rtol=2e-3, atol=2e-3 * max(1.0, float(v.abs().max())))
+
+
+@pytest.mark.skipif(__import__("os").environ.get("VIDAR_STAGED") != "1",
+                    reason="written without a GPU for the staged VIDAR_MSDA_SKIP_DEAD kernels: tools/staged_variants.sh "
+                           "runs it with VIDAR_STAGED=1")
+@pytest.mark.parametrize("scatter", list(SCATTER))
+def test_rows_with_nan_locations_between_live_rows(scatter):
+    """queries whose every sample is NaN (the padded slots of the cross attention under VIDAR_SCA_PAD_NAN=1) mixed with
+    live ones inside the same waves: their rows are 0, the live rows equal the run without them bit for bit"""
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    value, sh, loc, w = M.make_case(5, 3, shapes, 333, P=8)
+    dead = torch.zeros(3, 333, dtype=torch.bool)
+    dead[:, ::3] = True; dead[1, 100:200] = True; dead[2, -40:] = True
+    loc_nan = loc.clone(); loc_nan[dead] = float("nan")
+    lsi = M.level_start_index(shapes).cuda()
+    go = torch.randn(3, 333, 256, generator=torch.Generator().manual_seed(6))
+    go[dead] = 0.0                                   # what the scatter-back's backward hands to padded slots
+    args = (value.cuda(), sh.cuda(), lsi)
+    out_ref = F._msda_forward(*args, loc.cuda(), w.cuda())
+    out = F._msda_forward(*args, loc_nan.cuda(), w.cuda())
+    d = dead.cuda()
+    assert float(out[d].abs().max()) == 0.0
+    assert torch.equal(out[~d], out_ref[~d])
+    gv, gl, gw = F._msda_backward(*args, loc_nan.cuda(), w.cuda(), go.cuda(), binned=SCATTER[scatter])
+    gv0, gl0, gw0 = F._msda_backward(*args, loc.cuda(), w.cuda(), go.cuda(), binned=SCATTER[scatter])
+    assert float(gl[d].abs().max()) == 0.0 and float(gw[d].abs().max()) == 0.0
+    assert torch.equal(gl[~d], gl0[~d]) and torch.equal(gw[~d], gw0[~d])
+    torch.testing.assert_close(gv, gv0, rtol=1e-4, atol=1e-5 * max(1.0, float(gv0.abs().max())))   # zero grad_out rows add 0

@@ -10,6 +10,8 @@ set -u
 cd "$(dirname "$0")/.."
 out=gpurun_out/first_call
 mkdir -p $out
+# the tests that were written without a GPU, first on the DEFAULT library (a failure here is a bug of the test)
+VIDAR_STAGED=1 timeout 300 python -m pytest tests/test_msda_gpu.py -q -m gpu -k nan_locations_between 2>&1 | tail -3 | tee $out/staged_tests_default_lib.log
 bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
 tail -60 $out/staged_variants.log
 # 2b. the staged stem kernel (BN + ReLU + max-pool in one pass): its bit-exactness test, then the whole-step A/B
