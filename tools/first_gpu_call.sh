@@ -4,7 +4,8 @@
 #     gpurun --timeout 1500 -- 'bash tools/first_gpu_call.sh'
 # 1. every staged compile-time variant: parity tests, then kernel timing next to the default build
 # 2. HBM traffic counters of the MSDA kernels on COHERENT reference points (the committed numbers are for random ones)
-# 3. whole-step A/B of the optimizer implementation
+# 3. whole-step A/Bs of the run-time switches (fused stem, NaN-padded cross-attention slots, fused AdamW)
+# In full this is about 30 GPU-minutes; `tools/staged_variants.sh <name>` runs one variant.
 # Everything lands in gpurun_out/first_call/ ; copy what is kept into profiles/.
 set -u
 cd "$(dirname "$0")/.."
@@ -16,25 +17,24 @@ bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
 tail -60 $out/staged_variants.log
 # 2b. the staged stem kernel (BN + ReLU + max-pool in one pass): its bit-exactness test, then the whole-step A/B
 VIDAR_STAGED=1 timeout 300 python -m pytest tests/test_dcn_gpu.py -q -m gpu -k fused_stem 2>&1 | tail -2 | tee $out/fused_stem_test.log
-for f in 0 1; do
-  VIDAR_FUSED_STEM=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \
-      2> /dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('fused_stem=$f', round(d['ms_per_step'], 2), 'ms/step')"
-done | tee $out/fused_stem_ab.log
-# 2c. padded SpatialCrossAttention slots with NaN anchors (skipped by the MSDA kernels): step parity, then the A/B
-VIDAR_SCA_PAD_NAN=1 timeout 600 python -m pytest tests/test_step_gpu.py tests/test_reference_golden_gpu.py -x -q -m gpu 2>&1 | tail -2 | tee $out/sca_pad_nan_test.log
-for v in default msda_skip; do
+step() {   # label, library (default | msda_skip), environment assignments -> one short bench run, ms/step + the MSDA op rows
+  local label="$1" v="$2"; shift 2
   [ -f vidar_amd/_staged/$v.so ] && cp vidar_amd/_staged/$v.so vidar_amd/libvidar_hip.so
-  for f in 0 1; do
-    VIDAR_SCA_PAD_NAN=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" --op-table \
-        2> $out/sca_pad_nan_${v}_$f.optable | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('lib=$v sca_pad_nan=$f', round(d['ms_per_step'], 2), 'ms/step')"
-    grep "msda_" $out/sca_pad_nan_${v}_$f.optable
-  done
-done | tee $out/sca_pad_nan_ab.log
+  env "$@" python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" --op-table \
+      2> $out/step_$label.optable | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('$label', round(d['ms_per_step'], 2), 'ms/step')"
+  grep "msda_\|affine_act_fwd\|stem_" $out/step_$label.optable | cut -c1-110
+}
+# 2c. padded SpatialCrossAttention slots with NaN anchors (skipped by the MSDA kernels): step parity first
+VIDAR_SCA_PAD_NAN=1 timeout 600 python -m pytest tests/test_step_gpu.py tests/test_reference_golden_gpu.py -x -q -m gpu 2>&1 | tail -2 | tee $out/sca_pad_nan_test.log
+# 3. whole-step A/Bs against ONE baseline run (10 steps each, ~1 min per run)
+{
+  step baseline default VIDAR_NOOP=1
+  step fused_stem default VIDAR_FUSED_STEM=1
+  step sca_pad_nan default VIDAR_SCA_PAD_NAN=1
+  step msda_skip msda_skip VIDAR_NOOP=1
+  step msda_skip+sca_pad_nan msda_skip VIDAR_SCA_PAD_NAN=1
+  step fused_adamw default VIDAR_FUSED_ADAMW=1
+} | tee $out/step_ab.log
 [ -f vidar_amd/_staged/default.so ] && cp vidar_amd/_staged/default.so vidar_amd/libvidar_hip.so
-# 3. optimizer: foreach AdamW (default) vs torch's fused AdamW
-for f in 0 1; do
-  VIDAR_FUSED_ADAMW=$f python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-rooflines --extra-configs "" \
-      2> /dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('fused_adamw=$f', round(d['ms_per_step'], 2), 'ms/step')"
-done | tee $out/fused_adamw_ab.log
 bash tools/pmc_pass.sh $out/pmc_msda_coherent "FETCH_SIZE WRITE_SIZE TCC_HIT,TCC_MISS" python tools/kbench.py msda_coherent > $out/pmc_msda_coherent.log 2>&1
 ls $out/pmc_msda_coherent 2>/dev/null && head -20 $out/pmc_msda_coherent/*.csv
