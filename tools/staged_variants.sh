@@ -21,6 +21,7 @@ dcn_coord4|dcn.hip|-DVIDAR_DCN_COORD_BATCH=4|tests/test_dcn_gpu.py|dcn|col2im
 dcn_coord8|dcn.hip|-DVIDAR_DCN_COORD_BATCH=8|tests/test_dcn_gpu.py|dcn|col2im
 dcn_segscan|dcn.hip|-DVIDAR_DCN_SEGMENTED_SCAN=1|tests/test_dcn_gpu.py|dcn|col2im
 ray_early|ray_march.hip|-DVIDAR_RAY_EARLY_EXIT=1|tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py tests/test_reference_golden_gpu.py|ray|ray_
+lr_copies8|latent_render.hip|-DVIDAR_LR_COPIES=8|tests/test_latent_render_gpu.py tests/test_step_gpu.py|lr|lr_
 msda_skip|msda.hip|-DVIDAR_MSDA_SKIP_DEAD=1|tests/test_msda_gpu.py tests/test_step_gpu.py|msda|msda
 aa_ilp2|affine_act.hip|-DVIDAR_AA_ILP=2|tests/test_dcn_gpu.py|affine|affine
 aa_ilp4|affine_act.hip|-DVIDAR_AA_ILP=4|tests/test_dcn_gpu.py|affine|affine
@@ -33,6 +34,8 @@ TABLE
 #  dcn_coord*  offset / mask gradient: the loads of 4 / 8 channels issued together (today: 3 loads, wait, 256 times)
 #  dcn_segscan col2im reverse map: one scan workgroup per (image, tap) list instead of per image
 #  ray_early   leave the 512-waypoint loops after the run of live waypoints (on average 3.9 of 16 passes are needed)
+#  lr_copies8  LatentRendering backward: 8 private copies of the gradient maps + a sum kernel -- 8 x fewer atomics per hot
+#              address (all rays start at the BEV centre) for the same total: tells contention from atomic rate
 #  msda_skip   MSDA forward / grad_loc kernels: an item without a live sample issues no corner loads (pays off together with
 #              VIDAR_SCA_PAD_NAN=1, timed in tools/first_gpu_call.sh; alone it only adds the check: expect +-0)
 #  aa_ilp*     frozen BN + residual + ReLU: 2 / 4 float4 per thread, all loads first
@@ -59,7 +62,7 @@ use() {   # name, file, flags -> installs the variant library
 
 echo "=================== default build"
 if [ -f $staged/default.so ]; then cp $staged/default.so $lib; else python -m vidar_amd.build > /dev/null 2>&1; fi
-timeout 300 python tools/kbench.py dvr dcn affine ray 2>&1 | grep -i "render\|im2col\|col2im\|affine\|ray_" | cut -c1-160
+timeout 300 python tools/kbench.py dvr dcn affine ray lr msda 2>&1 | grep -i "render\|im2col\|col2im\|affine\|ray_\|lr_\|msda" | cut -c1-160
 
 variants | while IFS='|' read -r name file flags tests kb pat; do
   [ "$want" = all ] || [ "$want" = "$name" ] || continue
