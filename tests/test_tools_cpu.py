@@ -46,3 +46,23 @@ def test_pretune_merge_adds_only_new_shapes_and_refuses_other_library_versions(t
     import pytest
     with pytest.raises(SystemExit):
         pt.merge(str(other))
+
+
+def test_devcode_kernel_parser_and_resource_name_shortening():
+    """tools/devcode.py splits an llvm-objdump listing into per-kernel instruction lists without the address / encoding
+    comments (so that two builds compare equal when only addresses moved); tools/kernel_resources.py shortens names"""
+    sys.path.insert(0, str(ROOT / "tools"))          # devcode imports kernel_resources from its own directory
+    kernel_resources = _load("kernel_resources")
+    devcode = _load("devcode")
+    text = ["", "0000000000001000 <_ZN1a3fooEv>:",
+            "\ts_load_dwordx2 s[0:1], s[4:5], 0x0                         // 000000001000: C0060002 00000000",
+            "\ts_endpgm                                                   // 000000001008: BF810000",
+            "0000000000001100 <_ZN1a3barEv>:",
+            "\tv_mov_b32_e32 v0, 0                                        // 000000001100: 7E000280"]
+    k = devcode.kernels(text)
+    assert list(k) == ["_ZN1a3fooEv", "_ZN1a3barEv"]
+    assert k["_ZN1a3fooEv"] == ["s_load_dwordx2 s[0:1], s[4:5], 0x0", "s_endpgm"]
+    moved = [ln.replace("000000001", "000000009") for ln in text]
+    assert devcode.kernels(moved)["_ZN1a3fooEv"] == k["_ZN1a3fooEv"]
+    assert kernel_resources.short("void (anonymous namespace)::dvr_render_kernel<256>(float const*, int)") == "dvr_render_kernel<256>"
+    assert kernel_resources.short("(anonymous namespace)::msda_fwd_kernel(float const*, long const*)") == "msda_fwd_kernel"
