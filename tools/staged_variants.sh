@@ -23,6 +23,7 @@ dcn_segscan|dcn.hip|-DVIDAR_DCN_SEGMENTED_SCAN=1|tests/test_dcn_gpu.py|dcn|col2i
 ray_early|ray_march.hip|-DVIDAR_RAY_EARLY_EXIT=1|tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py tests/test_reference_golden_gpu.py|ray|ray_
 lr_copies8|latent_render.hip|-DVIDAR_LR_COPIES=8|tests/test_latent_render_gpu.py tests/test_step_gpu.py|lr|lr_
 msda_skip|msda.hip|-DVIDAR_MSDA_SKIP_DEAD=1|tests/test_msda_gpu.py tests/test_step_gpu.py|msda|msda
+msda_nt|msda.hip|-DVIDAR_MSDA_NT_LOADS=1|tests/test_msda_gpu.py|msda msda_coherent|msda
 aa_ilp2|affine_act.hip|-DVIDAR_AA_ILP=2|tests/test_dcn_gpu.py|affine|affine
 aa_ilp4|affine_act.hip|-DVIDAR_AA_ILP=4|tests/test_dcn_gpu.py|affine|affine
 TABLE
@@ -38,6 +39,8 @@ TABLE
 #              address (all rays start at the BEV centre) for the same total: tells contention from atomic rate
 #  msda_skip   MSDA forward / grad_loc kernels: an item without a live sample issues no corner loads (pays off together with
 #              VIDAR_SCA_PAD_NAN=1, timed in tools/first_gpu_call.sh; alone it only adds the check: expect +-0)
+#  msda_nt     MSDA gathers (forward, grad_loc): corner lines with the non-temporal cache policy -- the gathers miss the
+#              vector L1 on almost every line, and 0.43 ms is what fill-then-deliver costs at 64 B/clk (delivery alone: 0.23)
 #  aa_ilp*     frozen BN + residual + ReLU: 2 / 4 float4 per thread, all loads first
 
 build_variant() {   # file, flags

@@ -248,8 +248,20 @@ __device__ __forceinline__ void corner_records(const GLevels& lv, float* rec, in
   __syncthreads();
 }
 
+#ifndef VIDAR_MSDA_NT_LOADS
+#define VIDAR_MSDA_NT_LOADS 0               // staged: corner lines fetched with the non-temporal (streaming) cache policy
+#endif
 __device__ __forceinline__ float4 ldv(const float* __restrict__ value, unsigned byte_off) {
+#if VIDAR_MSDA_NT_LOADS
+  // the gathers miss the vector L1 on almost every line (L2 hit rate ~50 % on random points, every line used once per
+  // wave): the measured 0.43 ms is what "fill the line, then deliver it" costs at 64 B/clk, twice the delivery alone.
+  // A streaming load does not have to keep the line.
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(value) + byte_off));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(value) + byte_off);
+#endif
 }
 
 __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
