@@ -17,6 +17,8 @@ variants() { cat <<'TABLE'
 dvr_pipe|dvr_family.hip|-DVIDAR_DVR_PIPELINED_SIGMA|tests/test_dvr_gpu.py tests/test_fullsize_parity_gpu.py tests/test_dropin_gpu.py|dvr|render
 dcn_cp8|dcn.hip|-DVIDAR_DCN_CP=8|tests/test_dcn_gpu.py|dcn|im2col
 dcn_cp4|dcn.hip|-DVIDAR_DCN_CP=4|tests/test_dcn_gpu.py|dcn|im2col
+dcn_nt|dcn.hip|-DVIDAR_DCN_NT_STORES=1|tests/test_dcn_gpu.py|dcn|im2col
+dcn_cp8_nt|dcn.hip|-DVIDAR_DCN_CP=8 -DVIDAR_DCN_NT_STORES=1|tests/test_dcn_gpu.py|dcn|im2col
 dcn_coord4|dcn.hip|-DVIDAR_DCN_COORD_BATCH=4|tests/test_dcn_gpu.py|dcn|col2im
 dcn_coord8|dcn.hip|-DVIDAR_DCN_COORD_BATCH=8|tests/test_dcn_gpu.py|dcn|col2im
 dcn_segscan|dcn.hip|-DVIDAR_DCN_SEGMENTED_SCAN=1|tests/test_dcn_gpu.py|dcn|col2im
@@ -32,6 +34,8 @@ TABLE
 #  dvr_pipe    a sample's density is consumed one commit later (dvr_march.h): bit-identical arithmetic, the load gets a
 #              whole traversal step to arrive; expect the most at <= 1 wave per SIMD (30 k rays)
 #  dcn_cp8/4   im2col channels per thread: 16 = 85 VGPRs, 27 scalar registers parked in VGPR lanes, 5 waves; 8 = 52 / 0 / 8
+#  dcn_nt      im2col column stores with the non-temporal policy (the 71 MB input is fetched 4 x from HBM today: the
+#              1.28 GB write stream evicts the planes the next taps re-read)
 #  dcn_coord*  offset / mask gradient: the loads of 4 / 8 channels issued together (today: 3 loads, wait, 256 times)
 #  dcn_segscan col2im reverse map: one scan workgroup per (image, tap) list instead of per image
 #  ray_early   leave the 512-waypoint loops after the run of live waypoints (on average 3.9 of 16 passes are needed)

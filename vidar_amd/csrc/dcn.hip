@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 #define VIDAR_DCN_CP 16          // channels per thread; 8 needs 52 instead of 85 VGPRs and no scalar spills (tools/staged_variants.sh)
 #endif
 constexpr int kCP = VIDAR_DCN_CP;
+#ifndef VIDAR_DCN_NT_STORES
+#define VIDAR_DCN_NT_STORES 0    // im2col: column stores with the non-temporal policy
+#endif
 #ifndef VIDAR_DCN_SEGMENTED_SCAN
 #define VIDAR_DCN_SEGMENTED_SCAN 0  // col2im reverse map: one scan workgroup per (image, tap) list instead of per image
 #endif
@@ -202,7 +205,17 @@ __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __res
     }
 #pragma unroll
     for (int c = 0; c < kCP; ++c)
-      if (c < nc) out[(size_t)c * KP + (size_t)t * P] = f.wt0 * a[c].x + f.wt1 * a[c].y + f.wb0 * b[c].x + f.wb1 * b[c].y;
+      if (c < nc) {
+        const float v = f.wt0 * a[c].x + f.wt1 * a[c].y + f.wb0 * b[c].x + f.wb1 * b[c].y;
+#if VIDAR_DCN_NT_STORES
+        // staged: the column matrix is written once and read by the GEMM much later (1.28 GB per call at stage 3); the
+        // counters show the 71 MB input fetched 4 x from HBM (profiles/r03_pmc_dcn) -- the write stream evicts the
+        // planes the next taps re-read.  Streaming stores leave them in L2.
+        __builtin_nontemporal_store(v, out + (size_t)c * KP + (size_t)t * P);
+#else
+        out[(size_t)c * KP + (size_t)t * P] = v;
+#endif
+      }
   }
 }
 
