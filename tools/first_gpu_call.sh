@@ -17,6 +17,7 @@ bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
 tail -60 $out/staged_variants.log
 # 2b. the staged stem kernel (BN + ReLU + max-pool in one pass): its bit-exactness test, then the whole-step A/B
 VIDAR_STAGED=1 timeout 300 python -m pytest tests/test_dcn_gpu.py -q -m gpu -k fused_stem 2>&1 | tail -2 | tee $out/fused_stem_test.log
+timeout 300 python tools/kbench.py stem 2>&1 | grep stem | tee $out/kbench_stem.log
 step() {   # label, library (default | msda_skip), environment assignments -> one short bench run, ms/step + the MSDA op rows
   local label="$1" v="$2"; shift 2
   [ -f vidar_amd/_staged/$v.so ] && cp vidar_amd/_staged/$v.so vidar_amd/libvidar_hip.so
@@ -30,6 +31,7 @@ VIDAR_SCA_PAD_NAN=1 timeout 600 python -m pytest tests/test_step_gpu.py tests/te
 {
   step baseline default VIDAR_NOOP=1
   step fused_stem default VIDAR_FUSED_STEM=1
+  step stem_s2d default VIDAR_STEM_S2D=1
   step sca_pad_nan default VIDAR_SCA_PAD_NAN=1
   step msda_skip msda_skip VIDAR_NOOP=1
   step msda_skip+sca_pad_nan msda_skip VIDAR_SCA_PAD_NAN=1
