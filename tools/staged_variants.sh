@@ -23,6 +23,8 @@ dcn_coord4|dcn.hip|-DVIDAR_DCN_COORD_BATCH=4|tests/test_dcn_gpu.py|dcn|col2im
 dcn_coord8|dcn.hip|-DVIDAR_DCN_COORD_BATCH=8|tests/test_dcn_gpu.py|dcn|col2im
 dcn_segscan|dcn.hip|-DVIDAR_DCN_SEGMENTED_SCAN=1|tests/test_dcn_gpu.py|dcn|col2im
 ray_early|ray_march.hip|-DVIDAR_RAY_EARLY_EXIT=1|tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py tests/test_reference_golden_gpu.py|ray|ray_
+ray_copies8|ray_march.hip|-DVIDAR_RAY_COPIES=8|tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py tests/test_step_gpu.py|ray|ray_
+ray_early_copies8|ray_march.hip|-DVIDAR_RAY_EARLY_EXIT=1 -DVIDAR_RAY_COPIES=8|tests/test_ray_ops_gpu.py tests/test_head_loss_gpu.py|ray|ray_
 lr_copies8|latent_render.hip|-DVIDAR_LR_COPIES=8|tests/test_latent_render_gpu.py tests/test_step_gpu.py|lr|lr_
 msda_skip|msda.hip|-DVIDAR_MSDA_SKIP_DEAD=1|tests/test_msda_gpu.py tests/test_step_gpu.py|msda|msda
 msda_nt|msda.hip|-DVIDAR_MSDA_NT_LOADS=1|tests/test_msda_gpu.py|msda msda_coherent|msda
@@ -39,6 +41,9 @@ TABLE
 #  dcn_coord*  offset / mask gradient: the loads of 4 / 8 channels issued together (today: 3 loads, wait, 256 times)
 #  dcn_segscan col2im reverse map: one scan workgroup per (image, tap) list instead of per image
 #  ray_early   leave the 512-waypoint loops after the run of live waypoints (on average 3.9 of 16 passes are needed)
+#  ray_copies8 ray_ce / ray_gumbel backward: 8 private copies of the gradient volume + a sum kernel (all rays of a frame start
+#              at the sensor origin: ~190 hot addresses take ~5 M atomics per ray_ce_bwd launch); the kbench line includes the
+#              memset + sum of the copies -- read the kernel's own time from a rocprofv3 --kernel-trace if it is close
 #  lr_copies8  LatentRendering backward: 8 private copies of the gradient maps + a sum kernel -- 8 x fewer atomics per hot
 #              address (all rays start at the BEV centre) for the same total: tells contention from atomic rate
 #  msda_skip   MSDA forward / grad_loc kernels: an item without a live sample issues no corner loads (pays off together with

@@ -141,6 +141,18 @@ constexpr float kNegInf = -__builtin_inff();
 #ifndef VIDAR_RAY_EARLY_EXIT
 #define VIDAR_RAY_EARLY_EXIT 0
 #endif
+// Staged, default 1 = off: like VIDAR_LR_COPIES of latent_render.hip.  Every ray of a frame starts at the sensor origin,
+// so the first waypoints of all rays of a frame scatter onto the same 8-27 voxels (210 000 rays x ~3 waypoints x 8
+// corners onto ~190 addresses in one ray_ce_bwd launch: if an address retires one atomic per ~25 ns that alone is the
+// launch's 0.66 ms).  With VIDAR_RAY_COPIES = n the backward kernels add into n private copies of the gradient volume
+// (workgroup i -> copy i mod n) and a small kernel sums them.
+#ifndef VIDAR_RAY_COPIES
+#define VIDAR_RAY_COPIES 1
+#endif
+#if VIDAR_RAY_COPIES > 1
+constexpr int kRayCopies = VIDAR_RAY_COPIES;
+#endif
+
 struct RunTracker {
   bool seen = false;
   // true when the pass just finished (wave-uniform `live` = some lane had an unmasked waypoint) ends the run
@@ -229,7 +241,11 @@ __global__ __launch_bounds__(kThreads) void ray_ce_bwd_kernel(
   if (ray.f < 0 || t0.masked) return;
   const size_t slice = (size_t)ray.f * v.Z * v.Y * v.X;
   const float* vol = sigma + slice;
+#if VIDAR_RAY_COPIES > 1
+  float* gvol = grad_sigma + (size_t)(blockIdx.x % kRayCopies) * v.F * v.Z * v.Y * v.X + slice;
+#else
   float* gvol = grad_sigma + slice;
+#endif
   const float lse = lse_in[r];
   if (lane == 0) tri_scatter(gvol, t0, g * (expf(tri_load(vol, t0) - lse) - 1.f));
   const int cx = lane & 1;
@@ -318,7 +334,11 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
   if (ray.f < 0) return;
   const size_t slice = (size_t)ray.f * v.Z * v.Y * v.X;
   const float* vol = sigma + slice;
+#if VIDAR_RAY_COPIES > 1
+  float* gvol = grad_sigma + (size_t)(blockIdx.x % kRayCopies) * v.F * v.Z * v.Y * v.X + slice;
+#else
   float* gvol = grad_sigma + slice;
+#endif
   const float pd = aux[(size_t)r * 3 + 0], pn = aux[(size_t)r * 3 + 1], lse = aux[(size_t)r * 3 + 2];
   const int cx = lane & 1;
 #if VIDAR_RAY_EARLY_EXIT
@@ -392,6 +412,30 @@ inline dim3 rm_grid(int R) { return dim3((R + kRaysPerBlock - 1) / kRaysPerBlock
 
 }  // namespace
 
+#if VIDAR_RAY_COPIES > 1
+namespace {
+__global__ __launch_bounds__(256) void ray_sum_copies_kernel(const float* __restrict__ copies, float* __restrict__ out,
+                                                             size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = copies[i];
+  for (int c = 1; c < kRayCopies; ++c) a += copies[(size_t)c * n + i];
+  out[i] = a;
+}
+float* g_ray_scratch = nullptr;            // grown on demand, kept for the life of the process (experiment only)
+size_t g_ray_scratch_floats = 0;
+inline float* ray_scratch(size_t floats) {
+  if (floats > g_ray_scratch_floats) {
+    if (g_ray_scratch) (void)hipFree(g_ray_scratch);
+    g_ray_scratch = nullptr; g_ray_scratch_floats = 0;
+    if (hipMalloc(&g_ray_scratch, floats * sizeof(float)) != hipSuccess) return nullptr;
+    g_ray_scratch_floats = floats;
+  }
+  return g_ray_scratch;
+}
+}  // namespace
+#endif
+
 extern "C" {
 
 int vidar_ray_ce_fwd_f32(const float* sigma, const float* origin, const float* gt_pts,
@@ -417,8 +461,19 @@ int vidar_ray_ce_bwd_f32(const float* sigma, const float* origin, const float* g
   if (e != hipSuccess) return (int)e;
   if (R == 0) return 0;
   VolDims v{F, Z, Y, X};
+#if VIDAR_RAY_COPIES > 1
+  const size_t n = (size_t)F * Z * Y * X;
+  float* sc = ray_scratch(n * kRayCopies);
+  if (!sc) return (int)hipErrorOutOfMemory;
+  e = hipMemsetAsync(sc, 0, sizeof(float) * n * kRayCopies, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(ray_ce_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, gt_pts, tindex, lse, grad_ce,
+                     sc, R, v, step);
+  hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc, grad_sigma, n);
+#else
   hipLaunchKernelGGL(ray_ce_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, gt_pts,
                      tindex, lse, grad_ce, grad_sigma, R, v, step);
+#endif
   return vidar_last_error();
 }
 
@@ -445,8 +500,19 @@ int vidar_ray_gumbel_bwd_f32(const float* sigma, const float* origin, const floa
   if (e != hipSuccess) return (int)e;
   if (R == 0) return 0;
   VolDims v{F, Z, Y, X};
+#if VIDAR_RAY_COPIES > 1
+  const size_t n = (size_t)F * Z * Y * X;
+  float* sc = ray_scratch(n * kRayCopies);
+  if (!sc) return (int)hipErrorOutOfMemory;
+  e = hipMemsetAsync(sc, 0, sizeof(float) * n * kRayCopies, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(ray_gumbel_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, pts, tindex, aux,
+                     grad_dist, sc, R, v, step);
+  hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc, grad_sigma, n);
+#else
   hipLaunchKernelGGL(ray_gumbel_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, pts,
                      tindex, aux, grad_dist, grad_sigma, R, v, step);
+#endif
   return vidar_last_error();
 }
 
