@@ -15,6 +15,17 @@ mkdir -p $out
 VIDAR_STAGED=1 timeout 300 python -m pytest tests/test_msda_gpu.py -q -m gpu -k nan_locations_between 2>&1 | tail -3 | tee $out/staged_tests_default_lib.log
 bash tools/staged_variants.sh > $out/staged_variants.log 2>&1
 tail -60 $out/staged_variants.log
+# 1b. the private-copies experiments: the kernels' own times (the kbench lines include the memset and the sum of the copies)
+for v in default ray_copies8 lr_copies8; do
+  [ -f vidar_amd/_staged/$v.so ] || continue
+  cp vidar_amd/_staged/$v.so vidar_amd/libvidar_hip.so
+  rm -rf /tmp/prof_$v
+  ( cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -o run -- \
+      python $OLDPWD/tools/kbench.py ray lr ) > $out/prof_$v.log 2>&1
+  f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1)
+  echo "== $v"; [ -n "$f" ] && grep -i "ray_\|lr_\|sum_copies\|fillBuffer" "$f" | cut -d, -f1-4 | cut -c1-150
+done | tee $out/copies_kernel_times.log
+[ -f vidar_amd/_staged/default.so ] && cp vidar_amd/_staged/default.so vidar_amd/libvidar_hip.so
 # 2b. the staged stem kernel (BN + ReLU + max-pool in one pass): its bit-exactness test, then the whole-step A/B
 VIDAR_STAGED=1 timeout 300 python -m pytest tests/test_dcn_gpu.py -q -m gpu -k fused_stem 2>&1 | tail -2 | tee $out/fused_stem_test.log
 timeout 300 python tools/kbench.py stem 2>&1 | grep stem | tee $out/kbench_stem.log
