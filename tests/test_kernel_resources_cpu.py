@@ -14,8 +14,13 @@ SO = ROOT / "vidar_amd" / "libvidar_hip.so"
 def rows():
     if not SO.exists():
         pytest.skip("libvidar_hip.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    import hashlib
     import kernel_resources
-    return kernel_resources.table(SO)
+    before = hashlib.sha256(SO.read_bytes()).hexdigest()
+    out = kernel_resources.table(SO)
+    # reading the metadata must never touch the product library (llvm-objcopy rewrites its input when no output is named)
+    assert hashlib.sha256(SO.read_bytes()).hexdigest() == before
+    return out
 
 
 def test_every_kernel_is_wave64_without_scratch_or_vgpr_spills(rows):

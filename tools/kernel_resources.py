@@ -52,7 +52,9 @@ def short(name):
 def code_objects(so_path, work):
     """The gfx950 code objects of a HIP shared library: one clang offload bundle per translation unit in .hip_fatbin."""
     fat = work / "fat.bin"
-    subprocess.run([str(LLVM / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(so_path)], check=True)
+    # llvm-objcopy rewrites its INPUT in place when no output is named: always name one (never touch the library)
+    subprocess.run([str(LLVM / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(so_path),
+                    str(work / "objcopy_out.discard")], check=True)
     blob = fat.read_bytes()
     starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
     objs = []
