@@ -309,6 +309,44 @@ int vidar_ray_argmax_f32(const float* sigma, const float* origin, const float* p
  *           (vidar_dcn_col2im_workspace_bytes, scratch) and every destination pixel gathers its
  *           contributions -- no atomics on grad_x, fully written.  Same result up to fp32 summation order.
  * ------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------
+ * Matrix products of the hot path on the gfx950 matrix cores (csrc/gemm_mfma.hip), fp32 in HBM on both sides:
+ *     C[z] = act( (A[z] (M x K) * B[z] (K x N)) * scale + shift + residual[z] )      z = 0 .. batch-1
+ * Replaces the library GEMMs behind the reference's nn.Linear layers -- first of all the attention value projection
+ * (spatial_cross_attention.py:333-340 `value = self.value_proj(value)`, temporal_self_attention.py:197-208,
+ * vidar_decoder.py:452-460), then sampling_offsets / attention_weights / output_proj of the same modules, the mmcv
+ * FFN and the head MLPs -- and behind the 1x1 / deformable convolutions of the image backbone with the frozen
+ * BatchNorm (+ residual + ReLU) that follows them folded into the epilogue (config vidar_1_8_nusc_1future.py:88-106).
+ *   a_layout / b_layout: 0 = K-major (the contraction index is contiguous: element (m,k) at A[m*lda + k], element
+ *     (k,n) at B[n*ldb + k], i.e. an nn.Linear weight [N,K] as B), 1 = MN-major (element (m,k) at A[k*lda + m],
+ *     element (k,n) at B[k*ldb + n], i.e. an NCHW activation [C, H*W] as B).  C is row-major, C[m*ldc + n].
+ *     Any alignment of the row starts is accepted (4-byte), any M, N, K >= 1.
+ *   strideA/B/C/R: element offsets between batch items (0 = shared operand).
+ *   scale, shift: optional vectors indexed by n (vec_axis 0: the bias of F.linear) or by m (vec_axis 1: per output
+ *     channel of a convolution); residual: optional [M, N] tensor with leading dimension ldr; relu: 0/1.
+ *   precision: 0 = VIDAR_GEMM_F32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- the arithmetic
+ *     of the library kernels it replaces); 1 = VIDAR_GEMM_BF16X3: every operand element is split x = hi + lo into
+ *     two bf16 while it is staged (hi = rne(x), lo = rne(x - hi): 16 significand bits, relative error <= 2^-16) and
+ *     a product is lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The reference runs
+ *     these products in TF32 (11 significand bits; torch 1.10.1+cu111 defaults, README.md:96; tools/train.py:141-144
+ *     only disables it under `close_tf32`, which no ViDAR config sets; encoder.py:98-100 is the one opt-out and
+ *     stays fp32 here too).
+ *   reduce = 1: ONE output C = act(sum_z A[z]*B[z] ...) -- the batch items are summed and K is additionally split
+ *     (vidar_gemm_splits) so that a weight gradient fills the chip; partial products go to `workspace`
+ *     (vidar_gemm_workspace_bytes) as fp32 slabs and are summed in a fixed order: deterministic, no atomics.
+ * ------------------------------------------------------------------------- */
+#define VIDAR_GEMM_F32 0
+#define VIDAR_GEMM_BF16X3 1
+#define VIDAR_GEMM_K_MAJOR 0
+#define VIDAR_GEMM_MN_MAJOR 1
+int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, int64_t ldb, int b_layout, float* C,
+                   int64_t ldc, int M, int N, int K, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                   const float* scale, const float* shift, int vec_axis, const float* residual, int64_t ldr,
+                   int64_t strideR, int relu, int precision, int reduce, void* workspace, size_t workspace_bytes,
+                   void* stream);
+int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce);
+size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce);
+
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
                          int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
                          int dil, void* stream);

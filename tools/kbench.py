@@ -262,6 +262,65 @@ def bench_ray(which):
     report(f"ray_gumbel_bwd R={pts.shape[0]}", ms, 4 * (2 * 16 * 200 * 200 + pts.shape[0] * 4))
 
 
+def bench_gemm(which):
+    """the hot path's GEMM shapes: library (torch addmm / bmm, TunableOp off) vs csrc/gemm_mfma.hip in both modes.
+    TF/s is the effective fp32-product rate 2MNK / time."""
+    from vidar_amd import gemm as G
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1
+
+    def line(name, flops, nbytes, **ms):
+        d = {"op": name}
+        for k, v in ms.items():
+            d[k + "_ms"] = round(v, 4); d[k + "_TF"] = round(flops / v / 1e9, 1)
+        d["min_HBM_ms"] = round(nbytes / 8e9, 4)
+        print(json.dumps(d), flush=True)
+
+    # nn.Linear shapes: value_proj (SCA), TSA offsets, FFN, output_proj
+    for (M, K, N, tag) in ((184950, 256, 256, "value_proj SCA"), (80000, 256, 256, "value_proj TSA"),
+                           (40000, 512, 128, "tsa sampling_offsets"), (40000, 256, 512, "ffn.0"),
+                           (40000, 512, 256, "ffn.1"), (46080, 256, 512, "sca sampling_offsets")):
+        x, w, b = rnd(M, K), rnd(N, K) * 0.1, rnd(N)
+        gy = rnd(M, N)
+        fl = 2.0 * M * N * K
+        ms = dict(lib=timeit(lambda: torch.addmm(b, x, w.t())))
+        for m, p in (("f32", G.F32), ("bf16x3", G.BF16X3)):
+            ms[m] = timeit(lambda: G.linear_forward(x, w, b, False, p))
+        line(f"linear fwd [{M},{K}]x[{K},{N}] {tag}", fl, 4 * (M * K + M * N + N * K), **ms)
+        ms = dict(lib=timeit(lambda: gy @ w))
+        for m, p in (("f32", G.F32), ("bf16x3", G.BF16X3)):
+            ms[m] = timeit(lambda: G.linear_grad_input(gy, w, p))
+        line(f"linear dx  [{M},{N}]x[{N},{K}] {tag}", fl, 4 * (M * K + M * N + N * K), **ms)
+        ms = dict(lib=timeit(lambda: (x.t() @ gy).t()))
+        for m, p in (("f32", G.F32), ("bf16x3", G.BF16X3)):
+            ms[m] = timeit(lambda: G.linear_grad_weight(gy, x, p))
+        line(f"linear dw  [{N},{M}]x[{M},{K}] {tag}", fl, 4 * (M * K + M * N + N * K), **ms)
+    # backbone: out[b] = W [Co,Ci] x[b] [Ci,HW]
+    for (Bn, Co, Ci, HW, tag) in ((24, 1024, 256, 5800, "layer3 conv3"), (24, 256, 1024, 5800, "layer3 conv1"),
+                                  (24, 256, 2304, 5800, "layer3 dcn"), (24, 512, 128, 23200, "layer2 conv3"),
+                                  (24, 2048, 512, 1450, "layer4 conv3")):
+        w, x = rnd(Co, Ci) * 0.05, rnd(Bn, Ci, HW)
+        sc, sh, res = rnd(Co), rnd(Co), rnd(Bn, Co, HW)
+        fl = 2.0 * Bn * Co * Ci * HW
+        nb = 4 * (Bn * Ci * HW + Bn * Co * HW)
+        ms = dict(lib=timeit(lambda: torch.bmm(w.view(1, Co, Ci).expand(Bn, -1, -1), x)))
+        for m, p in (("f32", G.F32), ("bf16x3", G.BF16X3)):
+            ms[m] = timeit(lambda: G.conv_forward(w, x, precision=p))
+            ms[m + "_bn_res_relu"] = timeit(lambda: G.conv_forward(w, x, sc, sh, res, True, p))
+        line(f"conv fwd {Bn}x[{Co},{Ci}]x[{Ci},{HW}] {tag}", fl, nb, **ms)
+        gy = rnd(6, Co, HW); x6 = x[:6]
+        fl6 = fl / 4
+        ms = dict(lib=timeit(lambda: torch.bmm(w.view(1, Co, Ci).transpose(1, 2).expand(6, -1, -1), gy)))
+        for m, p in (("f32", G.F32), ("bf16x3", G.BF16X3)):
+            ms[m] = timeit(lambda: G.conv_grad_input(w, gy, p))
+        line(f"conv dx  6x[{Ci},{Co}]x[{Co},{HW}] {tag}", fl6, nb / 4, **ms)
+        ms = dict(lib=timeit(lambda: torch.bmm(gy, x6.transpose(1, 2)).sum(0)))
+        for m, p in (("f32", G.F32), ("bf16x3", G.BF16X3)):
+            ms[m] = timeit(lambda: G.conv_grad_weight(gy, x6, p))
+        line(f"conv dw  6x[{Co},{HW}]x[{HW},{Ci}] {tag}", fl6, nb / 4, **ms)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dvr", "knn", "msda", "lr", "ray"]
     print(json.dumps({"device": torch.cuda.get_device_name(0)}))

@@ -1,0 +1,437 @@
+// gemm_mfma.hip -- the hot path's matrix products on the gfx950 matrix cores, hand written.
+//
+//   C[z] = epilogue( A[z] (M x K)  *  B[z] (K x N) )        fp32 in HBM on both sides, fp32 accumulate
+//
+// Two arithmetic modes share every line of the tile machinery:
+//   VIDAR_GEMM_F32    v_mfma_f32_32x32x2_f32 : exact fp32 products, one rounding per product (the arithmetic of
+//                     the rocBLAS / hipBLASLt kernels it replaces), 1/16 of the bf16 matrix rate
+//   VIDAR_GEMM_BF16X3 every operand is split while it is staged, x = hi + lo with hi = bf16(x), lo = bf16(x - hi),
+//                     and a product is three v_mfma_f32_32x32x16_bf16 into ONE fp32 accumulator:
+//                     lo*hi + hi*lo + hi*hi.  hi + lo carries 16 significand bits (relative error <= 2^-16;
+//                     TF32 -- what the reference's pinned torch 1.10 runs these products in on A100,
+//                     README.md:96, tools/train.py:141-144 -- carries 11), the dropped lo*lo term is <= 2^-16 of
+//                     a product, at 3/16 of the fp32 matrix-core cost.
+//
+// Operand layouts (the four combinations cover forward, grad-input and grad-weight of nn.Linear on [rows, C]
+// activations and of 1x1 / deformable convolutions on NCHW activations without a transposed copy):
+//   K-major : the contraction index is contiguous   (x [M,K] of F.linear; weight [N,K] as B)
+//   MN-major: the row / column index is contiguous  (NCHW activations [C, H*W] as B; grad_out^T as A)
+//
+// Tile: 128 x 128 x (32 | 16) per 256-thread workgroup, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of
+// 32 x 32 (64 accumulator registers).  Staging is global -> registers -> (split) -> LDS with the next k-tile's global
+// loads in flight under the MFMAs.  LDS images, identical geometry in both modes (a "unit" is one dword = one fp32
+// k or one bf16 k-pair):
+//   K-major  operand: [128 rows][16 units + 4 pad]   row stride 80 B: ds_read_b128 fragments are conflict free
+//                     (slot stride 5 is odd, and each of the instruction's four 16-lane groups covers all 16
+//                     residues of the row index)
+//   MN-major operand: [16 units][128 rows + 8 pad]   four ds_read_b32 per fragment, 32 consecutive dwords per group
+// A lane's fragment is always the four units 8*s + 4*(lane>>5) + {0..3} of its row -- in bf16 mode they ARE the
+// eight consecutive k of one 32x32x16 operand, in fp32 mode they feed four 32x32x2 MFMAs whose two k slots
+// (lane halves) take units t and 4 + t; both operands use the same assignment, which is all a contraction needs.
+// The MFMA is issued with the operands swapped (rows := columns of B, columns := rows of A) so that a lane's
+// accumulator registers 4q..4q+3 are four CONSECUTIVE n of one row m: the epilogue stores 16 bytes per lane.
+//
+// Epilogue: y = relu?( acc * scale[m|n] + shift[m|n] + residual[m,n] ) -- the bias of F.linear, the frozen
+// BatchNorm + residual + ReLU that follows every 1x1 convolution of the ResNet bottlenecks
+// (config vidar_1_8_nusc_1future.py:88-106: norm_eval, requires_grad False), the FFN's ReLU.
+// Split-K / batch-reduced products (weight gradients) write fp32 slabs and a second kernel sums them in a
+// fixed order (deterministic; no atomics).
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "vidar_hip.h"
+#include "vidar_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 4-byte aligned: rows of H*W = 1450 floats
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, THREADS = 256;
+constexpr int UNITS = 16;                 // dwords of k per row per k-step
+constexpr int KM_STRIDE = UNITS + 4;      // dwords per row of a K-major image
+constexpr int MN_STRIDE = 128 + 8;        // dwords per unit row of an MN-major image
+constexpr int IMG_DWORDS = 128 * KM_STRIDE;   // 2560 >= 16 * 136 = 2176: one size for both kinds
+constexpr int PREC_F32 = 0, PREC_BF16X3 = 1;
+constexpr int LAY_K = 0, LAY_MN = 1;
+
+struct GemmArgs {
+  const float* A; const float* B; float* C;
+  int64_t lda, ldb, ldc, sA, sB, sC;
+  int M, N, K;
+  int splits, k_chunk;          // blockIdx.z = batch * splits + split ; the split covers k in [split*k_chunk, +k_chunk)
+  int slabs;                    // 1: every z writes the slab ws[z] (no epilogue); 0: z = batch item, epilogue to C
+  const float* scale; const float* shift; int vec_axis;      // 0: indexed by n, 1: indexed by m
+  const float* residual; int64_t ldr, sR;
+  int relu;
+  int tiles_m, tiles_n, m_fastest;
+};
+
+// ---- staging: 16 (fp32 mode: 8) floats per operand per thread ----------------------------------------------------
+template <int PREC>
+struct Staged {               // the registers a thread holds between its global loads and its LDS writes
+  static constexpr int CH = (PREC == PREC_BF16X3) ? 2 : 1;   // chunks of 8 floats
+  f32x4 v[CH][2];
+};
+
+// K-major operand: element (row, k) at P[row * ld + k].  bf16 mode: k-step 32, chunk c = rows (tid>>2) + 64c, eight k
+// from (tid&3)*8.  fp32 mode: k-step 16, row tid>>1, eight k from (tid&1)*8.
+template <int PREC>
+__device__ __forceinline__ void load_kmajor(Staged<PREC>& s, const float* __restrict__ P, int64_t ld, int row0, int rows,
+                                            int k0, int kend, int tid) {
+#pragma unroll
+  for (int c = 0; c < Staged<PREC>::CH; ++c) {
+    const int r = (PREC == PREC_BF16X3) ? (tid >> 2) + 64 * c : (tid >> 1);
+    const int k = k0 + ((PREC == PREC_BF16X3) ? (tid & 3) * 8 : (tid & 1) * 8);
+    const int row = row0 + r;
+    const float* p = P + (int64_t)row * ld + k;
+    if (row < rows && k + 8 <= kend) {
+      s.v[c][0] = *(const f32x4u*)p;
+      s.v[c][1] = *(const f32x4u*)(p + 4);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s.v[c][j >> 2][j & 3] = (row < rows && k + j < kend) ? p[j] : 0.0f;
+    }
+  }
+}
+
+// MN-major operand: element (k, col) at P[k * ld + col].  bf16 mode: item = tid + 256c, column quad item&31, k pair
+// item>>5 (two rows of four columns).  fp32 mode: items tid and tid + 256: column quad item&31, k = item>>5.
+template <int PREC>
+__device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, const float* __restrict__ P, int64_t ld, int col0, int cols,
+                                             int k0, int kend, int tid) {
+#pragma unroll
+  for (int i = 0; i < Staged<PREC>::CH * 2; ++i) {
+    int col, k;
+    if (PREC == PREC_BF16X3) {
+      const int item = tid + 256 * (i >> 1);
+      col = col0 + (item & 31) * 4;
+      k = k0 + (item >> 5) * 2 + (i & 1);
+    } else {
+      const int item = tid + 256 * i;
+      col = col0 + (item & 31) * 4;
+      k = k0 + (item >> 5);
+    }
+    const float* p = P + (int64_t)k * ld + col;
+    f32x4 v;
+    if (k < kend && col + 4 <= cols) {
+      v = *(const f32x4u*)p;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (k < kend && col + j < cols) ? p[j] : 0.0f;
+    }
+    s.v[i >> 1][i & 1] = v;
+  }
+}
+
+// x = hi + lo: hi = bf16_rne(x), lo = bf16_rne(x - float(hi)) ; two values at a time (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  f32x2 x = {a, b};
+  bf16x2 h = __builtin_convertvector(x, bf16x2);
+  f32x2 r = x - __builtin_convertvector(h, f32x2);
+  bf16x2 l = __builtin_convertvector(r, bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// LDS writes.  `img` = the operand's image (bf16 mode: hi at img, lo at img + IMG_DWORDS).
+template <int PREC>
+__device__ __forceinline__ void store_kmajor(const Staged<PREC>& s, uint32_t* img, int tid) {
+  if (PREC == PREC_BF16X3) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int r = (tid >> 2) + 64 * c, u = (tid & 3) * 4;
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t h, l;
+        split2(s.v[c][j >> 1][(j & 1) * 2], s.v[c][j >> 1][(j & 1) * 2 + 1], h, l);
+        hi[j] = h; lo[j] = l;
+      }
+      *(u32x4*)(img + r * KM_STRIDE + u) = hi;
+      *(u32x4*)(img + IMG_DWORDS + r * KM_STRIDE + u) = lo;
+    }
+  } else {
+    const int r = tid >> 1, u = (tid & 1) * 8;
+    *(f32x4*)(img + r * KM_STRIDE + u) = s.v[0][0];
+    *(f32x4*)(img + r * KM_STRIDE + u + 4) = s.v[0][1];
+  }
+}
+
+template <int PREC>
+__device__ __forceinline__ void store_mnmajor(const Staged<PREC>& s, uint32_t* img, int tid) {
+  if (PREC == PREC_BF16X3) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int item = tid + 256 * c;
+      const int cq = (item & 31) * 4, u = item >> 5;
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t h, l;
+        split2(s.v[c][0][j], s.v[c][1][j], h, l);      // (k even, k odd) of column j
+        hi[j] = h; lo[j] = l;
+      }
+      *(u32x4*)(img + u * MN_STRIDE + cq) = hi;
+      *(u32x4*)(img + IMG_DWORDS + u * MN_STRIDE + cq) = lo;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int item = tid + 256 * i;
+      *(f32x4*)(img + (item >> 5) * MN_STRIDE + (item & 31) * 4) = s.v[0][i];
+    }
+  }
+}
+
+// a lane's fragment of row `row` (0..127 inside the tile) for sub-step s: units 8s + 4h + {0..3}
+template <int LAY>
+__device__ __forceinline__ u32x4 frag(const uint32_t* img, int row, int s, int h) {
+  if (LAY == LAY_K) return *(const u32x4*)(img + row * KM_STRIDE + 8 * s + 4 * h);
+  u32x4 f;
+  const uint32_t* p = img + (8 * s + 4 * h) * MN_STRIDE + row;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f[j] = p[j * MN_STRIDE];
+  return f;
+}
+
+template <int PREC, int ALAY, int BLAY>
+__global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
+  constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
+  constexpr int BK = (PREC == PREC_BF16X3) ? 32 : 16;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * IMGS * IMG_DWORDS];
+  uint32_t* imgA = lds;
+  uint32_t* imgB = lds + IMGS * IMG_DWORDS;
+
+  // workgroup -> tile.  Consecutive ids (after the XCD remap: one XCD's L2) walk the shorter tile axis first, so the
+  // big operand's strip is fetched from HBM once and re-read from L2 by the tiles that share it.
+  const int per_z = g.tiles_m * g.tiles_n;
+  const int nwg = per_z * (int)gridDim.y;
+  int id = blockIdx.x + blockIdx.y * per_z;
+  {
+    const int q = nwg >> 3, r = nwg & 7, x = id & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  const int z = id / per_z;
+  const int t = id - z * per_z;
+  const int tm = g.m_fastest ? t % g.tiles_m : t / g.tiles_n;
+  const int tn = g.m_fastest ? t / g.tiles_m : t % g.tiles_n;
+  const int batch = z / g.splits, split = z - batch * g.splits;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = split * g.k_chunk;
+  const int kend = min(g.K, kbeg + g.k_chunk);
+
+  const float* A = g.A + (int64_t)batch * g.sA;
+  const float* B = g.B + (int64_t)batch * g.sB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  Staged<PREC> sa, sb;
+  auto fetch = [&](int k0) {
+    if (ALAY == LAY_K) load_kmajor<PREC>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+    else load_mnmajor<PREC>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+    if (BLAY == LAY_K) load_kmajor<PREC>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+    else load_mnmajor<PREC>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
+    if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
+    __syncthreads();
+    if (k0 + BK < kend) fetch(k0 + BK);          // in flight under the MFMAs below
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fa[2][IMGS], fb[2][IMGS];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < IMGS; ++p) {
+          fa[i][p] = frag<ALAY>(imgA + p * IMG_DWORDS, wm + 32 * i + l31, s, h);
+          fb[i][p] = frag<BLAY>(imgB + p * IMG_DWORDS, wn + 32 * i + l31, s, h);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (PREC == PREC_BF16X3) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[i][0]), al = __builtin_bit_cast(bf16x8, fa[i][IMGS - 1]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[j][0]), bl = __builtin_bit_cast(bf16x8, fb[j][IMGS - 1]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, fb[j][0][u]),
+                                                               __builtin_bit_cast(float, fa[i][0][u]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds, per (i, j, q): row m = m0 + wm + 32i + l31, columns n = n0 + wn + 32j + 8q + 4h + {0..3}
+  float* C; int64_t ldc;
+  if (g.slabs) { C = g.C + (int64_t)z * g.M * g.N; ldc = g.N; }
+  else { C = g.C + (int64_t)batch * g.sC; ldc = g.ldc; }
+  const bool epi = !g.slabs;
+  const float* R = (epi && g.residual) ? g.residual + (int64_t)batch * g.sR : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm + 32 * i + l31;
+    if (m >= g.M) continue;
+    float sm = 1.0f, bm = 0.0f;
+    if (epi && g.vec_axis == 1) {
+      if (g.scale) sm = g.scale[m];
+      if (g.shift) bm = g.shift[m];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn + 32 * j + 8 * q + 4 * h;
+        if (n >= g.N) continue;
+        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        const bool full = n + 4 <= g.N;
+        if (epi) {
+          f32x4 sc = {sm, sm, sm, sm}, sh = {bm, bm, bm, bm}, rs = {0.f, 0.f, 0.f, 0.f};
+          if (g.vec_axis == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (n + e < g.N) {
+                if (g.scale) sc[e] = g.scale[n + e];
+                if (g.shift) sh[e] = g.shift[n + e];
+              }
+            }
+          }
+          if (R) {
+            const float* rp = R + (int64_t)m * g.ldr + n;
+            if (full) rs = *(const f32x4u*)rp;
+            else
+#pragma unroll
+              for (int e = 0; e < 4; ++e) if (n + e < g.N) rs[e] = rp[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float y = v[e] * sc[e] + sh[e] + rs[e];
+            v[e] = (g.relu && !(y > 0.0f)) ? 0.0f : y;
+          }
+        }
+        float* cp = C + (int64_t)m * ldc + n;
+        if (full) *(f32x4u*)cp = v;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[e] = v[e];
+      }
+  }
+}
+
+// C[m, n] = epilogue( sum_z slab[z][m, n] ), slabs summed in z order (deterministic)
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __restrict__ ws, int Z, GemmArgs g) {
+  const int64_t total = (int64_t)g.M * g.N;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    float a = 0.0f;
+    for (int z = 0; z < Z; ++z) a += ws[(int64_t)z * total + e];
+    const int m = (int)(e / g.N), n = (int)(e - (int64_t)m * g.N);
+    const int vi = g.vec_axis == 1 ? m : n;
+    float y = a * (g.scale ? g.scale[vi] : 1.0f) + (g.shift ? g.shift[vi] : 0.0f);
+    if (g.residual) y += g.residual[(int64_t)m * g.ldr + n];
+    g.C[(int64_t)m * g.ldc + n] = (g.relu && !(y > 0.0f)) ? 0.0f : y;
+  }
+}
+
+template <int PREC>
+void launch(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStream_t st) {
+  if (a_layout == LAY_K && b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_K>), grid, dim3(THREADS), 0, st, g);
+  else if (a_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_MN>), grid, dim3(THREADS), 0, st, g);
+  else if (b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_K>), grid, dim3(THREADS), 0, st, g);
+  else hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_MN>), grid, dim3(THREADS), 0, st, g);
+}
+
+// how many k-splits a reduced product gets: enough workgroups for ~2 per CU, k chunks of at least 4 k-steps
+int pick_splits(int M, int N, int K, int batch, int bk) {
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+  int s = (512 + tiles - 1) / tiles;
+  const int max_s = (K + 4 * bk - 1) / (4 * bk);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce) {
+  if (!reduce) return 1;
+  return pick_splits(M, N, K, batch, precision == PREC_BF16X3 ? 32 : 16);
+}
+
+size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce) {
+  if (!reduce) return 0;
+  const int s = vidar_gemm_splits(M, N, K, batch, precision, reduce);
+  if (batch * s == 1) return 0;
+  return (size_t)batch * s * M * N * sizeof(float);
+}
+
+int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, int64_t ldb, int b_layout, float* C,
+                   int64_t ldc, int M, int N, int K, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                   const float* scale, const float* shift, int vec_axis, const float* residual, int64_t ldr,
+                   int64_t strideR, int relu, int precision, int reduce, void* workspace, size_t workspace_bytes,
+                   void* stream) {
+  VIDAR_ENTER();
+  if (A == nullptr || B == nullptr || C == nullptr || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return VIDAR_ERR_BAD_ARG;
+  if ((a_layout != LAY_K && a_layout != LAY_MN) || (b_layout != LAY_K && b_layout != LAY_MN)) return VIDAR_ERR_BAD_ARG;
+  if (precision != PREC_F32 && precision != PREC_BF16X3) return VIDAR_ERR_BAD_ARG;
+  if (vec_axis != 0 && vec_axis != 1) return VIDAR_ERR_BAD_ARG;
+  if (lda < (a_layout == LAY_K ? K : M) || ldb < (b_layout == LAY_K ? K : N) || ldc < N) return VIDAR_ERR_BAD_ARG;
+  if (residual != nullptr && ldr < N) return VIDAR_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int bk = precision == PREC_BF16X3 ? 32 : 16;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
+  g.M = M; g.N = N; g.K = K;
+  g.scale = scale; g.shift = shift; g.vec_axis = vec_axis; g.residual = residual; g.ldr = ldr; g.sR = strideR;
+  g.relu = relu;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  g.m_fastest = M < N;
+  g.splits = reduce ? pick_splits(M, N, K, batch, bk) : 1;
+  g.k_chunk = ((K + g.splits - 1) / g.splits + bk - 1) / bk * bk;
+  const int Z = batch * g.splits;
+  g.slabs = (reduce && Z > 1) ? 1 : 0;
+  if ((int64_t)g.tiles_m * g.tiles_n > 0x7fffffff / 2 || Z > 65535) return VIDAR_ERR_BAD_ARG;
+  GemmArgs k = g;
+  if (g.slabs) {
+    if (workspace == nullptr || workspace_bytes < (size_t)Z * M * N * sizeof(float)) return VIDAR_ERR_BAD_ARG;
+    k.C = (float*)workspace;
+  }
+  dim3 grid(g.tiles_m * g.tiles_n, Z);
+  if (precision == PREC_BF16X3) launch<PREC_BF16X3>(k, a_layout, b_layout, grid, st);
+  else launch<PREC_F32>(k, a_layout, b_layout, grid, st);
+  if (g.slabs) {
+    const int64_t total = (int64_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, Z, g);
+  }
+  return vidar_last_error();
+}
+
+}  // extern "C"
