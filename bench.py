@@ -68,6 +68,9 @@ def parse():
                     help="comma-separated `config[@samples_per_gpu]` entries timed after the main one in the same run "
                          "(short records under `configs`): BASELINE.json's other named configs -- the north star's "
                          "target sentence names vidar_1_8_nusc_3future; OpenScene = 8 cameras; @2 = per-GPU batch 2")
+    ap.add_argument("--gemm", choices=["lib", "f32", "bf16x3"], default=None,
+                    help="what the Linear / 1x1-convolution products of the main record run on (default: vidar_amd.gemm."
+                         "mode(), i.e. $VIDAR_GEMM or the package default); extra configs take it as `name@spg:gemm`")
     ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--extra-warmup", type=int, default=2)
     ap.add_argument("--cpu-baseline-only", choices=["ops", "step", "full"], help=argparse.SUPPRESS)
@@ -438,8 +441,28 @@ def make_batch(cfg, args, rank, dev, spg=None):
     return batch
 
 
-def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None):
-    """build the model of one named config, time `steps` training steps -> dict(elapsed, ops, ddp, cfg)"""
+def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, gemm_mode=None):
+    """build the model of one named config, time `steps` training steps -> dict(elapsed, ops, ddp, cfg, peak_mem_gb)"""
+    from vidar_amd import gemm as G
+    prev = G.set_mode(gemm_mode or G.mode())
+    try:
+        torch.cuda.reset_peak_memory_stats(dev)
+        r = _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg)
+        r["gemm"] = G.mode()
+        # the number next to the reference's only published figure for this path (README.md:143-148: ~63 GB for
+        # vidar_1_8_nusc_3future, ~34 GB for its memory-efficient variant, per A100)
+        r["peak_mem_gb"] = torch.cuda.max_memory_allocated(dev) / 1e9
+        r["peak_reserved_gb"] = torch.cuda.max_memory_reserved(dev) / 1e9
+        return r
+    finally:
+        G.set_mode(prev)
+
+
+GEMM_DTYPE = {"lib": "f32", "f32": "f32",
+              "bf16x3": "f32 storage, bf16x3 MFMA products (16-bit significand >= TF32), f32 accumulate"}
+
+
+def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None):
     from vidar_amd import gemm_tuning
     from vidar_amd import train as T
     from vidar_amd._lib import TIMER
@@ -502,20 +525,43 @@ def main():
     grouped = dist.is_available() and dist.is_initialized()
     spg = args.samples_per_gpu
 
-    main_run = run_config(args.config, args, rank, local, world, dev, args.steps, args.warmup, with_markers=True)
+    main_run = run_config(args.config, args, rank, local, world, dev, args.steps, args.warmup, with_markers=True,
+                          gemm_mode=args.gemm)
     elapsed, ops, cfg = main_run["elapsed"], main_run["ops"], main_run["cfg"]
     extras = []
-    for entry in [c for c in args.extra_configs.split(",") if c and c != args.config]:
-        name, _, xs = entry.partition("@")
+    for entry in [c for c in args.extra_configs.split(",") if c]:
+        head, _, xgemm = entry.partition(":")
+        name, _, xs = head.partition("@")
         xspg = int(xs) if xs else spg
-        r = run_config(name, args, rank, local, world, dev, args.extra_steps, args.extra_warmup, with_markers=False,
-                       spg=xspg)
+        xgemm = xgemm or None
+        if name == args.config and xspg == spg and (xgemm or main_run["gemm"]) == main_run["gemm"]:
+            continue
+        # an extra config must never cost the main measurement its record: a failure (e.g. out of memory at a large
+        # per-GPU batch) is agreed on across ranks and written into the entry
+        err = None
+        try:
+            r = run_config(name, args, rank, local, world, dev, args.extra_steps, args.extra_warmup, with_markers=False,
+                           spg=xspg, gemm_mode=xgemm)
+        except Exception as e:                                              # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"[:300]
+            r = None
+            torch.cuda.empty_cache()
+        if grouped:
+            flag = torch.tensor([1.0 if err else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if float(flag) > 0 and err is None:
+                err = "failed on another rank"
+        if err:
+            extras.append({"config": name, "samples_per_gpu": xspg, "gemm": xgemm or main_run["gemm"], "error": err})
+            continue
         rec = {"config": name, "samples_per_gpu": xspg, "value": world * xspg * args.extra_steps / r["elapsed"],
                "unit": "samples/s", "ms_per_step": r["elapsed"] / args.extra_steps * 1e3, "steps": args.extra_steps,
                "warmup": args.extra_warmup, "n_gpus": world, "global_batch": world * xspg,
-               "cameras": r["cfg"]["num_cams"], "img_hw": list(r["cfg"]["img_hw"])}
+               "cameras": r["cfg"]["num_cams"], "img_hw": list(r["cfg"]["img_hw"]), "gemm": r["gemm"],
+               "dtype": GEMM_DTYPE[r["gemm"]], "peak_mem_gb": round(r["peak_mem_gb"], 2),
+               "peak_reserved_gb": round(r["peak_reserved_gb"], 2)}
         if r["ops"]:
-            dn, dv = max(((k, v) for k, v in r["ops"].items() if not k.startswith(("dcn_", "affine_act", "stem_"))),
+            dn, dv = max(((k, v) for k, v in r["ops"].items() if not k.startswith(("dcn_", "affine_act", "stem_", "gemm_"))),
                          key=lambda kv: kv[1]["total_ms"])
             ach = dv["bytes_per_call"] / (dv["avg_ms"] * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "kernel": dn, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -529,21 +575,23 @@ def main():
         if args.op_table:
             for k, v in sorted(ops.items(), key=lambda kv: -kv[1]["total_ms"]):
                 gb = v["bytes_per_call"] / v["avg_ms"] / 1e6 if v["avg_ms"] > 0 else 0
+                unit = "GFLOP/s" if k.startswith("gemm_") else "GB/s"      # the gemm spans carry 2MNK, not bytes
                 print(f"{k:28s} calls/step {v['calls'] / args.steps:6.1f}  avg {v['avg_ms']:8.3f} ms  "
-                      f"total/step {v['total_ms'] / args.steps:8.2f} ms  alg {gb:8.1f} GB/s", file=sys.stderr)
+                      f"total/step {v['total_ms'] / args.steps:8.2f} ms  alg {gb:8.1f} {unit}", file=sys.stderr)
         # `roofline`: the dominant kernel of the SURVEY 8(a) hot path (MSDA / latent render / ray march / chamfer);
         # the backbone's kernels (row f-1: dcn_*, affine_act_*) compete in `roofline_step_dominant`
-        hot = {k: v for k, v in ops.items() if not k.startswith(("dcn_", "affine_act", "stem_"))} or ops
+        hot = {k: v for k, v in ops.items() if not k.startswith(("dcn_", "affine_act", "stem_", "gemm_"))} or ops
         dom_name, dom = max(hot.items(), key=lambda kv: kv[1]["total_ms"])
         achieved = dom["bytes_per_call"] / (dom["avg_ms"] * 1e-3) / 1e9
-        all_name, all_dom = max(ops.items(), key=lambda kv: kv[1]["total_ms"])
+        all_name, all_dom = max(((k, v) for k, v in ops.items() if not k.startswith("gemm_")), key=lambda kv: kv[1]["total_ms"])
         all_ach = all_dom["bytes_per_call"] / (all_dom["avg_ms"] * 1e-3) / 1e9
         hip_ms = sum(v["total_ms"] for v in ops.values()) / args.steps
         out = {
             "metric": "train samples/sec (6-cam->BEV step)", "value": world * spg * args.steps / elapsed,
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": GEMM_DTYPE[main_run["gemm"]], "data": "synthetic", "gemm": main_run["gemm"],
+            "peak_mem_gb": round(main_run["peak_mem_gb"], 2), "peak_reserved_gb": round(main_run["peak_reserved_gb"], 2),
             "config": {"workload": (f"{args.config}: images [1,5,{cfg['num_cams']},3,{cfg['img_hw'][0]}x"
                                     f"{cfg['img_hw'][1]}] -> ResNet101-DCNv2 + FPN -> " if not args.no_backbone
                                     else f"{args.config} (no image backbone): FPN pyramids -> ")

@@ -1,0 +1,79 @@
+"""GPU: the model on the hand-written MFMA GEMM (vidar_amd.gemm modes "f32" and "bf16x3") holds every check the
+library-GEMM path holds, at UNCHANGED tolerances: the reference-module goldens (encoder stack, forward_train losses +
+gradients, forward_test chamfer distance per future frame within 1e-3 of the reference's value), the whole-step
+comparison with the CPU oracle, and the image backbone (fused conv + frozen BN + residual + ReLU epilogues, the
+deformable convolution's column product) against the library path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from vidar_amd import gemm as G  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_reference_goldens_hold_on_the_mfma_gemm_path(mode):
+    import test_reference_golden_gpu as R
+    with G.use(mode):
+        R.test_encoder_stack_matches_reference_modules(True)
+        R.test_head_v1_forward_matches_reference()
+        R.test_forward_test_chamfer_per_future_frame_within_1e_3_of_reference()
+        R.test_forward_train_losses_and_gradients_match_reference()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_whole_step_matches_cpu_oracle_on_the_mfma_gemm_path(mode):
+    import test_step_gpu as S
+    with G.use(mode):
+        S.test_hip_step_matches_cpu_oracle_step("vidar_1_8_nusc_1future", 1)
+
+
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-4), ("bf16x3", 2e-3)])
+def test_backbone_fused_epilogues_match_library_path(mode, tol):
+    """ResNet101-DCNv2 + FPN, 2 images 96 x 160: outputs and parameter / input gradients of the MFMA path (1x1
+    convolutions with BN + residual + ReLU in the GEMM epilogue, DCN column product with BN + ReLU in the epilogue)
+    against the library path (bmm + affine_act).  tol: relative L2 over ~100 layers of fp32 (2e-4) / of 16-bit-significand
+    products (2e-3)."""
+    from vidar_amd.configs import get_config
+    from vidar_amd.plugin.registry import build_backbone, build_neck
+    cfg = get_config("vidar_1_8_nusc_1future", with_backbone=True)["model"]
+    torch.manual_seed(0)
+    bb, neck = build_backbone(cfg["img_backbone"]).cuda(), build_neck(cfg["img_neck"]).cuda()
+    with torch.no_grad():                                  # non-trivial frozen statistics and DCN offsets
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, device="cuda", generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, device="cuda", generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, device="cuda", generator=g) * 0.5 + 0.25)
+                m.bias.copy_(torch.randn(m.bias.shape, device="cuda", generator=g) * 0.1)
+            if hasattr(m, "conv_offset"):
+                m.conv_offset.weight.copy_(torch.randn(m.conv_offset.weight.shape, device="cuda", generator=g) * 0.01)
+    bb.train(); neck.train()
+    x = torch.randn(2, 3, 96, 160, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    params = [p for p in list(bb.parameters()) + list(neck.parameters()) if p.requires_grad]
+    outs, grads = {}, {}
+    for m in ("lib", mode):
+        with G.use(m):
+            y = neck(bb(x))
+            w = [torch.randn(t.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3 + i))
+                 for i, t in enumerate(y)]
+            loss = sum((a * b).sum() for a, b in zip(y, w))
+            grads[m] = torch.autograd.grad(loss, params)
+            outs[m] = [t.detach() for t in y]
+    for a, b in zip(outs[mode], outs["lib"]):
+        assert _rel_l2(a, b) < tol, _rel_l2(a, b)
+    num = sum(float(((a.double() - b.double()) ** 2).sum()) for a, b in zip(grads[mode], grads["lib"]))
+    den = sum(float((b.double() ** 2).sum()) for b in grads["lib"])
+    assert (num / den) ** 0.5 < 5 * tol, (num / den) ** 0.5
+
+
+def test_bench_records_name_the_gemm_arithmetic():
+    import bench
+    assert bench.GEMM_DTYPE["lib"] == "f32" and bench.GEMM_DTYPE["f32"] == "f32"
+    assert "bf16x3" in bench.GEMM_DTYPE["bf16x3"] and "f32 accumulate" in bench.GEMM_DTYPE["bf16x3"]

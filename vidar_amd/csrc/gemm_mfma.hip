@@ -82,7 +82,8 @@ struct Staged {               // the registers a thread holds between its global
 
 // K-major operand: element (row, k) at P[row * ld + k].  bf16 mode: k-step 32, chunk c = rows (tid>>2) + 64c, eight k
 // from (tid&3)*8.  fp32 mode: k-step 16, row tid>>1, eight k from (tid&1)*8.
-template <int PREC>
+// FULL: the workgroup's whole tile and k range are inside the matrix (decided once per workgroup): no per-lane checks.
+template <int PREC, bool FULL>
 __device__ __forceinline__ void load_kmajor(Staged<PREC>& s, const float* __restrict__ P, int64_t ld, int row0, int rows,
                                             int k0, int kend, int tid) {
 #pragma unroll
@@ -91,7 +92,7 @@ __device__ __forceinline__ void load_kmajor(Staged<PREC>& s, const float* __rest
     const int k = k0 + ((PREC == PREC_BF16X3) ? (tid & 3) * 8 : (tid & 1) * 8);
     const int row = row0 + r;
     const float* p = P + (int64_t)row * ld + k;
-    if (row < rows && k + 8 <= kend) {
+    if (FULL || (row < rows && k + 8 <= kend)) {
       s.v[c][0] = *(const f32x4u*)p;
       s.v[c][1] = *(const f32x4u*)(p + 4);
     } else {
@@ -103,7 +104,7 @@ __device__ __forceinline__ void load_kmajor(Staged<PREC>& s, const float* __rest
 
 // MN-major operand: element (k, col) at P[k * ld + col].  bf16 mode: item = tid + 256c, column quad item&31, k pair
 // item>>5 (two rows of four columns).  fp32 mode: items tid and tid + 256: column quad item&31, k = item>>5.
-template <int PREC>
+template <int PREC, bool FULL>
 __device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, const float* __restrict__ P, int64_t ld, int col0, int cols,
                                              int k0, int kend, int tid) {
 #pragma unroll
@@ -120,7 +121,7 @@ __device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, const float* __res
     }
     const float* p = P + (int64_t)k * ld + col;
     f32x4 v;
-    if (k < kend && col + 4 <= cols) {
+    if (FULL || (k < kend && col + 4 <= cols)) {
       v = *(const f32x4u*)p;
     } else {
 #pragma unroll
@@ -201,6 +202,60 @@ __device__ __forceinline__ u32x4 frag(const uint32_t* img, int row, int s, int h
   return f;
 }
 
+template <int PREC, int ALAY, int BLAY, bool FULL>
+__device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], const float* __restrict__ A, const float* __restrict__ B,
+                                         const GemmArgs& g, uint32_t* imgA, uint32_t* imgB, int m0, int n0, int kbeg,
+                                         int kend, int tid) {
+  constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
+  constexpr int BK = (PREC == PREC_BF16X3) ? 32 : 16;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int l31 = lane & 31, h = lane >> 5;
+  Staged<PREC> sa, sb;
+  auto fetch = [&](int k0) {
+    if (ALAY == LAY_K) load_kmajor<PREC, FULL>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+    else load_mnmajor<PREC, FULL>(sa, A, g.lda, m0, g.M, k0, kend, tid);
+    if (BLAY == LAY_K) load_kmajor<PREC, FULL>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+    else load_mnmajor<PREC, FULL>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
+    if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
+    __syncthreads();
+    if (k0 + BK < kend) fetch(k0 + BK);          // in flight under the MFMAs below
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fa[2][IMGS], fb[2][IMGS];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < IMGS; ++p) {
+          fa[i][p] = frag<ALAY>(imgA + p * IMG_DWORDS, wm + 32 * i + l31, s, h);
+          fb[i][p] = frag<BLAY>(imgB + p * IMG_DWORDS, wn + 32 * i + l31, s, h);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (PREC == PREC_BF16X3) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[i][0]), al = __builtin_bit_cast(bf16x8, fa[i][IMGS - 1]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[j][0]), bl = __builtin_bit_cast(bf16x8, fb[j][IMGS - 1]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[i][j], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, fb[j][0][u]),
+                                                               __builtin_bit_cast(float, fa[i][0][u]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();
+  }
+}
+
 template <int PREC, int ALAY, int BLAY>
 __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
@@ -241,49 +296,10 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  Staged<PREC> sa, sb;
-  auto fetch = [&](int k0) {
-    if (ALAY == LAY_K) load_kmajor<PREC>(sa, A, g.lda, m0, g.M, k0, kend, tid);
-    else load_mnmajor<PREC>(sa, A, g.lda, m0, g.M, k0, kend, tid);
-    if (BLAY == LAY_K) load_kmajor<PREC>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
-    else load_mnmajor<PREC>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
-  };
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
-    if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
-    __syncthreads();
-    if (k0 + BK < kend) fetch(k0 + BK);          // in flight under the MFMAs below
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 fa[2][IMGS], fb[2][IMGS];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < IMGS; ++p) {
-          fa[i][p] = frag<ALAY>(imgA + p * IMG_DWORDS, wm + 32 * i + l31, s, h);
-          fb[i][p] = frag<BLAY>(imgB + p * IMG_DWORDS, wn + 32 * i + l31, s, h);
-        }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (PREC == PREC_BF16X3) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[i][0]), al = __builtin_bit_cast(bf16x8, fa[i][IMGS - 1]);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[j][0]), bl = __builtin_bit_cast(bf16x8, fb[j][IMGS - 1]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[i][j], 0, 0, 0);
-          } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, fb[j][0][u]),
-                                                               __builtin_bit_cast(float, fa[i][0][u]), acc[i][j], 0, 0, 0);
-          }
-        }
-    }
-    __syncthreads();
-  }
+  // interior workgroups (all of them for the hot shapes) run the loop without a single per-lane bounds check
+  const bool full = m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
+  if (full) mainloop<PREC, ALAY, BLAY, true>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, tid);
+  else mainloop<PREC, ALAY, BLAY, false>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, tid);
 
   // ---- epilogue: lane holds, per (i, j, q): row m = m0 + wm + 32i + l31, columns n = n0 + wn + 32j + 8q + 4h + {0..3}
   float* C; int64_t ldc;

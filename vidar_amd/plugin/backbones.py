@@ -17,6 +17,7 @@ from torch.autograd.function import once_differentiable
 
 from .registry import BACKBONES, NECKS
 from .._lib import lib, check, ptr, stream_of, TIMER
+from .. import gemm as G
 
 
 def dcn_col2im(grad_cols, x, offset, mask, kh, kw, stride, pad, dil, Ho, Wo, gather=True):
@@ -39,8 +40,12 @@ def dcn_col2im(grad_cols, x, offset, mask, kh, kw, stride, pad, dil, Ho, Wo, gat
 
 
 class _ModulatedDeformConv(Function):
+    """gemm_mode "lib": the column product is a library bmm; "f32" / "bf16x3": csrc/gemm_mfma.hip, and the frozen
+    BatchNorm + ReLU that follows the convolution in a bottleneck (scale / shift given) rides in its epilogue."""
+
     @staticmethod
-    def forward(ctx, x, offset, mask, weight, bias, stride, pad, dil):
+    def forward(ctx, x, offset, mask, weight, bias, stride, pad, dil, gemm_mode="lib", scale=None, shift=None,
+                relu=False):
         x, offset, mask = x.float().contiguous(), offset.float().contiguous(), mask.float().contiguous()
         N, C, H, W = x.shape
         Cout, _, kh, kw = weight.shape
@@ -50,30 +55,54 @@ class _ModulatedDeformConv(Function):
         with TIMER.span("dcn_im2col", 4 * (x.numel() + offset.numel() + mask.numel() + cols.numel())):
             check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(offset), ptr(mask), ptr(cols), N, C, H, W, Ho,
                                              Wo, kh, kw, stride, pad, dil, stream_of(x)), "dcn_im2col")
-        # bmm with a broadcast (stride-0) weight: torch.matmul(2-D, 3-D) would transpose-copy `cols`
-        out = torch.bmm(weight.reshape(1, Cout, -1).expand(N, -1, -1), cols)
-        if bias is not None:
-            out = out + bias.view(1, -1, 1)
-        ctx.save_for_backward(x, offset, mask, weight, cols)
-        ctx.cfg = (stride, pad, dil, Ho, Wo, bias is not None)
+        fused = scale is not None
+        if gemm_mode == "lib":
+            assert not fused
+            # bmm with a broadcast (stride-0) weight: torch.matmul(2-D, 3-D) would transpose-copy `cols`
+            out = torch.bmm(weight.reshape(1, Cout, -1).expand(N, -1, -1), cols)
+            if bias is not None:
+                out = out + bias.view(1, -1, 1)
+        else:
+            sh = shift
+            if bias is not None:
+                sh = bias.float() if not fused else (shift + bias.float() * scale)
+            out = G.conv_forward(weight.reshape(Cout, -1), cols, scale, sh, None, relu, G.precision_of(gemm_mode))
+        ctx.save_for_backward(x, offset, mask, weight, cols, scale, out if (fused and relu) else None)
+        ctx.cfg = (stride, pad, dil, Ho, Wo, bias is not None, gemm_mode, fused, relu)
         return out.view(N, Cout, Ho, Wo)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        x, offset, mask, weight, cols = ctx.saved_tensors
-        stride, pad, dil, Ho, Wo, has_bias = ctx.cfg
+        x, offset, mask, weight, cols, scale, y = ctx.saved_tensors
+        stride, pad, dil, Ho, Wo, has_bias, gemm_mode, fused, relu = ctx.cfg
         N, C, H, W = x.shape
         Cout, _, kh, kw = weight.shape
-        go = grad_out.contiguous().view(N, Cout, Ho * Wo)
-        grad_weight = torch.bmm(go, cols.transpose(1, 2)).sum(0).reshape(weight.shape)
-        grad_cols = torch.bmm(weight.reshape(1, Cout, -1).transpose(1, 2).expand(N, -1, -1), go)
+        go = grad_out.float().contiguous().view(N, Cout, Ho * Wo)
+        if fused:                                   # through the ReLU mask and the frozen BN scale
+            go = _affine_act_backward(go, y if relu else go, scale, relu, False)[0]
+        if gemm_mode == "lib":
+            grad_weight = torch.bmm(go, cols.transpose(1, 2)).sum(0).reshape(weight.shape)
+            grad_cols = torch.bmm(weight.reshape(1, Cout, -1).transpose(1, 2).expand(N, -1, -1), go)
+        else:
+            prec = G.precision_of(gemm_mode)
+            grad_weight = G.conv_grad_weight(go, cols, prec).reshape(weight.shape) if ctx.needs_input_grad[3] else None
+            grad_cols = G.conv_grad_input(weight.reshape(Cout, -1), go, prec)
         gx, goff, gm = dcn_col2im(grad_cols, x, offset, mask, kh, kw, stride, pad, dil, Ho, Wo)
-        return gx, goff, gm, grad_weight, (go.sum((0, 2)) if has_bias else None), None, None, None
+        return (gx, goff, gm, grad_weight, (go.sum((0, 2)) if has_bias else None), None, None, None, None, None, None,
+                None)
 
 
-def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1):
-    return _ModulatedDeformConv.apply(x, offset, mask, weight, bias, int(stride), int(padding), int(dilation))
+def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, bn=None, relu=False):
+    """bn: a FrozenBN whose affine (+ `relu`) is folded into the GEMM epilogue when the MFMA GEMM path is on
+    (vidar_amd.gemm.mode() != "lib") -- the caller must then NOT apply it again (see `Bottleneck.forward`)"""
+    m = G.mode() if x.is_cuda else "lib"
+    scale = shift = None
+    if bn is not None:
+        assert m != "lib"
+        scale, shift = bn._scale_shift()
+    return _ModulatedDeformConv.apply(x, offset, mask, weight, bias, int(stride), int(padding), int(dilation), m,
+                                      scale, shift, bool(relu))
 
 
 class ModulatedDeformConv2dPack(nn.Module):
@@ -95,12 +124,12 @@ class ModulatedDeformConv2dPack(nn.Module):
         nn.init.zeros_(self.conv_offset.weight)
         nn.init.zeros_(self.conv_offset.bias)
 
-    def forward(self, x):
+    def forward(self, x, bn=None, relu=False):
         out = self.conv_offset(x)
         o1, o2, mask = torch.chunk(out, 3, dim=1)
         offset = torch.cat((o1, o2), dim=1)
         return modulated_deform_conv2d(x, offset, torch.sigmoid(mask), self.weight, self.bias,
-                                       self.stride, self.padding, self.dilation)
+                                       self.stride, self.padding, self.dilation, bn=bn, relu=relu)
 
 
 class _AffineAct(Function):
@@ -124,14 +153,20 @@ class _AffineAct(Function):
     def backward(ctx, gy):
         y, scale = ctx.saved_tensors
         relu, has_res = ctx.cfg
-        gy = gy.float().contiguous()
-        N, C, H, W = y.shape
-        gx = torch.empty_like(y)
-        gres = torch.empty_like(y) if has_res else None
-        with TIMER.span("affine_act_bwd", 4 * y.numel() * (4 if has_res else 3)):
-            check(lib().vidar_affine_act_bwd_f32(ptr(gy), ptr(y), ptr(scale), ptr(gx), ptr(gres), N, C,
-                                                 H * W, int(relu), stream_of(y)), "affine_act_bwd")
+        gx, gres = _affine_act_backward(gy.float().contiguous(), y, scale, relu, has_res)
         return gx, None, None, gres, None
+
+
+def _affine_act_backward(gy, y, scale, relu, has_res):
+    """grad of y = act(x*scale[c] + shift[c] (+ residual)) w.r.t. x and residual; gy, y: [N, C, ...] contiguous"""
+    N, C = y.shape[:2]
+    HW = y.numel() // (N * C)
+    gx = torch.empty_like(y)
+    gres = torch.empty_like(y) if has_res else None
+    with TIMER.span("affine_act_bwd", 4 * y.numel() * (4 if has_res else 3)):
+        check(lib().vidar_affine_act_bwd_f32(ptr(gy), ptr(y), ptr(scale), ptr(gx), ptr(gres), N, C,
+                                             HW, int(relu), stream_of(y)), "affine_act_bwd")
+    return gx, gres
 
 
 class FrozenBN(nn.BatchNorm2d):
@@ -235,6 +270,48 @@ class Conv1x1(nn.Conv2d):
         return out.view(N, self.out_channels, H, W)
 
 
+class _Conv1x1BNAct(Function):
+    """act(bn(conv1x1(x)) + residual) with the frozen BatchNorm, the residual add and the ReLU in the epilogue of the
+    MFMA GEMM (csrc/gemm_mfma.hip): the [N, Cout, H*W] product is written once instead of written, re-read and
+    re-written by affine_act."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, residual, relu, precision):
+        x = x.float().contiguous()
+        N, C, H, W = x.shape
+        Cout = weight.shape[0]
+        res = residual.float().contiguous().view(N, Cout, H * W) if residual is not None else None
+        y = G.conv_forward(weight.reshape(Cout, C), x.view(N, C, H * W), scale, shift, res, relu, precision)
+        ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.cfg = (relu, residual is not None, precision)
+        return y.view(N, Cout, H, W)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, scale, y = ctx.saved_tensors
+        relu, has_res, precision = ctx.cfg
+        N, C, H, W = x.shape
+        Cout = weight.shape[0]
+        gy = gy.float().contiguous().view(N, Cout, H * W)
+        gz, gres = _affine_act_backward(gy, y if relu else gy, scale, relu, has_res)
+        gx = G.conv_grad_input(weight.reshape(Cout, C), gz, precision).view(N, C, H, W) if ctx.needs_input_grad[0] else None
+        gw = G.conv_grad_weight(gz, x.view(N, C, H * W), precision).view_as(weight) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, None, (gres.view(N, Cout, H, W) if has_res else None), None, None
+
+
+def conv1x1_bn_act(conv, bn, x, residual=None, relu=False):
+    """`bn(conv(x), residual, relu)` of a bias-free 1x1 convolution and a frozen BN; fused when the MFMA GEMM path is on"""
+    m = G.mode()
+    if (m == "lib" or not x.is_cuda or bn.weight.requires_grad or conv.bias is not None or conv.kernel_size != (1, 1)
+            or conv.padding != (0, 0) or conv.groups != 1):
+        return bn(conv(x), residual=residual, relu=relu)
+    if conv.stride != (1, 1):
+        x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
+    scale, shift = bn._scale_shift()
+    return _Conv1x1BNAct.apply(x, conv.weight, scale, shift, residual, bool(relu), G.precision_of(m))
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -254,10 +331,19 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), residual=identity, relu=True)
+        if self.downsample is None:
+            identity = x
+        elif len(self.downsample) == 2 and isinstance(self.downsample[1], FrozenBN):
+            identity = conv1x1_bn_act(self.downsample[0], self.downsample[1], x)
+        else:
+            identity = self.downsample(x)
+        out = conv1x1_bn_act(self.conv1, self.bn1, x, relu=True)
+        if (isinstance(self.conv2, ModulatedDeformConv2dPack) and G.mode() != "lib" and out.is_cuda
+                and not self.bn2.weight.requires_grad):
+            out = self.conv2(out, bn=self.bn2, relu=True)
+        else:
+            out = self.bn2(self.conv2(out), relu=True)
+        return conv1x1_bn_act(self.conv3, self.bn3, out, residual=identity, relu=True)
 
 
 @BACKBONES.register_module()

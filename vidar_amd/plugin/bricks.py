@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .registry import FEEDFORWARD_NETWORK, POSITIONAL_ENCODING
+from .. import gemm as _gemm
 
 
 def xavier_init(module, gain=1, bias=0, distribution="normal"):
@@ -67,6 +68,8 @@ class _LinearColsum(torch.autograd.Function):
         from .._lib import lib, check, ptr, stream_of
         x2, w = ctx.saved_tensors
         g2 = g if g.is_contiguous() else g.contiguous()
+        if g2.dtype != torch.float32 or g2.data_ptr() % 16:          # the column-sum kernel reads float4
+            g2 = g2.float().clone()
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = g2 @ w
@@ -83,12 +86,20 @@ class Linear(nn.Linear):
     gradient comes from `vidar_colsum_f32` (one HBM-rate pass) -- torch's generic reduction made ~250 calls / 6 ms of
     a training step out of these column sums."""
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
+        """relu=True: ReLU(linear(x)) -- in the epilogue of the MFMA GEMM when that path is on"""
         n = self.out_features
-        if (x.is_cuda and x.dtype == torch.float32 and self.bias is not None and self.bias.requires_grad
+        f32 = (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32
+               and (self.bias is None or self.bias.dtype == torch.float32) and not torch.is_autocast_enabled())
+        if f32 and _gemm.mode() != "lib" and x.numel() > 0:
+            # the hand-written matrix-core kernel (csrc/gemm_mfma.hip): exact fp32 ("f32") or split-bf16 ("bf16x3")
+            return _gemm.linear(x, self.weight, self.bias, relu=relu)
+        if (f32 and self.bias is not None and self.bias.requires_grad
                 and torch.is_grad_enabled() and n % 4 == 0 and (n // 4) & (n // 4 - 1) == 0 and n <= 4096):
-            return _LinearColsum.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias).view(*x.shape[:-1], n)
-        return F.linear(x, self.weight, self.bias)
+            y = _LinearColsum.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias).view(*x.shape[:-1], n)
+        else:
+            y = F.linear(x, self.weight, self.bias)
+        return F.relu(y, inplace=True) if relu else y
 
 
 @FEEDFORWARD_NETWORK.register_module()
@@ -112,13 +123,23 @@ class FFN(nn.Module):
         self.dropout_layer = nn.Identity()
         self.add_identity = add_identity
 
+    def _body(self, x):
+        """layers[:-1]; a (Linear, ReLU, Dropout) stage hands its ReLU to the Linear (GEMM epilogue on the MFMA path)"""
+        for stage in self.layers[:-1]:
+            if (isinstance(stage, nn.Sequential) and len(stage) == 3 and isinstance(stage[0], Linear)
+                    and isinstance(stage[1], nn.ReLU)):
+                x = stage[2](stage[0](x, relu=True))
+            else:
+                x = stage(x)
+        return x
+
     def forward(self, x, identity=None, fuse_norm=None):
         if fuse_norm is not None and self.add_identity and isinstance(self.layers[-1], nn.Dropout) \
                 and isinstance(self.dropout_layer, nn.Identity):
-            out = self.layers[:-1](x)                      # the closing Dropout moves into the fused tail
+            out = self._body(x)                            # the closing Dropout moves into the fused tail
             return drop_add_layernorm(out, x if identity is None else identity, fuse_norm, self.layers[-1].p,
                                       self.training)
-        out = self.layers(x)
+        out = self.layers[-1](self._body(x))
         if not self.add_identity:
             return self.dropout_layer(out)
         res = (x if identity is None else identity) + self.dropout_layer(out)
