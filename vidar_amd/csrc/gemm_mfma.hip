@@ -80,25 +80,21 @@ struct Staged {               // the registers a thread holds between its global
   f32x4 v[CH][2];
 };
 
-// K-major operand: element (row, k) at P[row * ld + k].  bf16 mode: k-step 32, chunk c = rows (tid>>2) + 64c, eight k
-// from (tid&3)*8.  fp32 mode: k-step 16, row tid>>1, eight k from (tid&1)*8.
-// FULL: the workgroup's whole tile and k range are inside the matrix (decided once per workgroup): no per-lane checks.
+// K-major operand: element (row, k) at P[row * ld + k].  Row tid>>1 in both modes; bf16 mode (k-step 32): sixteen k from
+// (tid&1)*16 (64 contiguous bytes per lane, one pointer); fp32 mode (k-step 16): eight k from (tid&1)*8.
 template <int PREC, bool FULL>
 __device__ __forceinline__ void load_kmajor(Staged<PREC>& s, const float* __restrict__ P, int64_t ld, int row0, int rows,
                                             int k0, int kend, int tid) {
+  constexpr int NK = Staged<PREC>::CH * 8;
+  const int row = row0 + (tid >> 1);
+  const int k = k0 + (tid & 1) * NK;
+  const float* p = P + (int64_t)row * ld + k;
+  if (FULL || (row < rows && k + NK <= kend)) {
 #pragma unroll
-  for (int c = 0; c < Staged<PREC>::CH; ++c) {
-    const int r = (PREC == PREC_BF16X3) ? (tid >> 2) + 64 * c : (tid >> 1);
-    const int k = k0 + ((PREC == PREC_BF16X3) ? (tid & 3) * 8 : (tid & 1) * 8);
-    const int row = row0 + r;
-    const float* p = P + (int64_t)row * ld + k;
-    if (FULL || (row < rows && k + 8 <= kend)) {
-      s.v[c][0] = *(const f32x4u*)p;
-      s.v[c][1] = *(const f32x4u*)(p + 4);
-    } else {
+    for (int c = 0; c < NK / 4; ++c) s.v[c >> 1][c & 1] = *(const f32x4u*)(p + 4 * c);
+  } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s.v[c][j >> 2][j & 3] = (row < rows && k + j < kend) ? p[j] : 0.0f;
-    }
+    for (int j = 0; j < NK; ++j) s.v[j >> 3][(j >> 2) & 1][j & 3] = (row < rows && k + j < kend) ? p[j] : 0.0f;
   }
 }
 
@@ -144,10 +140,10 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 // LDS writes.  `img` = the operand's image (bf16 mode: hi at img, lo at img + IMG_DWORDS).
 template <int PREC>
 __device__ __forceinline__ void store_kmajor(const Staged<PREC>& s, uint32_t* img, int tid) {
+  const int r = tid >> 1, u = (tid & 1) * 8;
   if (PREC == PREC_BF16X3) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int r = (tid >> 2) + 64 * c, u = (tid & 3) * 4;
+    for (int c = 0; c < 2; ++c) {          // chunk c: k 8c .. 8c+7 of the lane's sixteen -> units u + 4c .. +3
       u32x4 hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -155,11 +151,10 @@ __device__ __forceinline__ void store_kmajor(const Staged<PREC>& s, uint32_t* im
         split2(s.v[c][j >> 1][(j & 1) * 2], s.v[c][j >> 1][(j & 1) * 2 + 1], h, l);
         hi[j] = h; lo[j] = l;
       }
-      *(u32x4*)(img + r * KM_STRIDE + u) = hi;
-      *(u32x4*)(img + IMG_DWORDS + r * KM_STRIDE + u) = lo;
+      *(u32x4*)(img + r * KM_STRIDE + u + 4 * c) = hi;
+      *(u32x4*)(img + IMG_DWORDS + r * KM_STRIDE + u + 4 * c) = lo;
     }
   } else {
-    const int r = tid >> 1, u = (tid & 1) * 8;
     *(f32x4*)(img + r * KM_STRIDE + u) = s.v[0][0];
     *(f32x4*)(img + r * KM_STRIDE + u + 4) = s.v[0][1];
   }
@@ -284,10 +279,6 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
 
   const float* A = g.A + (int64_t)batch * g.sA;
   const float* B = g.B + (int64_t)batch * g.sB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-  const int l31 = lane & 31, h = lane >> 5;
-
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -298,10 +289,13 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
 
   // interior workgroups (all of them for the hot shapes) run the loop without a single per-lane bounds check
   const bool full = m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
-  if (full) mainloop<PREC, ALAY, BLAY, true>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, tid);
-  else mainloop<PREC, ALAY, BLAY, false>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, tid);
+  if (full) mainloop<PREC, ALAY, BLAY, true>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, threadIdx.x);
+  else mainloop<PREC, ALAY, BLAY, false>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, threadIdx.x);
 
   // ---- epilogue: lane holds, per (i, j, q): row m = m0 + wm + 32i + l31, columns n = n0 + wn + 32j + 8q + 4h + {0..3}
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int l31 = lane & 31, h = lane >> 5;
   float* C; int64_t ldc;
   if (g.slabs) { C = g.C + (int64_t)z * g.M * g.N; ldc = g.N; }
   else { C = g.C + (int64_t)batch * g.sC; ldc = g.ldc; }
