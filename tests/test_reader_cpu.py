@@ -270,6 +270,10 @@ def test_named_recipes_carry_their_dataset_settings():
     k = dataset_kwargs(get_config("vidar_1_8_nusc_3future"))
     assert k["rand_frame_interval"] == (-1, 1, 2) and k["voxel_size"] == (1.0,) * 3 and k["future_length"] == 4
     assert dataset_kwargs(get_config("vidar_1_8_nusc_3future"), test_mode=True)["future_length"] == 6
+    # the 1/8 stride is a TRAINING-split setting (vidar_1_8_nusc_1future.py:338-342 vs :345-368): evaluation covers the
+    # whole val split unless a stride is asked for explicitly
+    assert dataset_kwargs(get_config("vidar_1_8_nusc_1future"), test_mode=True)["load_frame_interval"] is None
+    assert dataset_kwargs(get_config("vidar_1_8_nusc_1future"), test_mode=True, test_stride=8)["load_frame_interval"] == 8
     assert dataset_kwargs(get_config("vidar_full_nusc_1future"))["load_frame_interval"] == 1
     k = dataset_kwargs(get_config("vidar_OpenScene_mini_full_3future"))
     assert k["dataset"] == "nuplan" and k["rand_frame_interval"] == (1,) and abs(k["img_scale"] - 2 / 3) < 1e-12

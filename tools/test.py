@@ -36,6 +36,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--ann-file", help="validation info pkl (data/nuscenes/nuscenes_infos_temporal_val.pkl)")
     ap.add_argument("--data-root", default="")
+    ap.add_argument("--eval-stride", type=int, default=None,
+                    help="evaluate every N-th usable val index (quick subset); default: the whole split, as the "
+                         "reference's data.test does")
     args = ap.parse_args(argv)
 
     from vidar_amd import checkpoint as C
@@ -78,7 +81,9 @@ def main(argv=None):
     if args.ann_file:
         from vidar_amd.configs import dataset_kwargs
         from vidar_amd.data import ViDARSequenceDataset
-        kw = dataset_kwargs(meta, test_mode=True)         # incl. the recipe's load_frame_interval (1/8 subsets)
+        # the whole val split, like the reference's data.test (no load_frame_interval there); --eval-stride N opts into
+        # a 1/N subset for a quick look
+        kw = dataset_kwargs(meta, test_mode=True, test_stride=args.eval_stride)
         kw["future_length"] = n_future
         ds = ViDARSequenceDataset(args.ann_file, data_root=args.data_root, **kw)
         n_samples = len(ds) if args.samples <= 0 else min(args.samples, len(ds))

@@ -115,16 +115,22 @@ def get_config(name, bev_h=200, bev_w=200, with_backbone=False):
                 data=dict(samples_per_gpu=1, workers_per_gpu=4, **v["data"]))
 
 
-def dataset_kwargs(meta, test_mode=False, file_cfg=None):
+def dataset_kwargs(meta, test_mode=False, file_cfg=None, test_stride=None):
     """-> keyword arguments of vidar_amd.data.ViDARSequenceDataset for a named recipe: the temporal augmentation
     (`rand_frame_interval`), the 1/8 subset stride (`load_frame_interval`), the GT voxel size of the point sampler and
     the future length of the split -- values of the released configs (vidar_1_8_nusc_1future.py:14-24, :294,
     :338-342; vidar_1_8_nusc_3future.py:14-28, :301; vidar_full_nusc_1future.py:14-24; OpenScene/
     vidar_OpenScene_mini_full_3future.py:14-28, :292).  `file_cfg`: a loaded released config file, whose own
-    `data.train` / `data.test` entries and point-sampler voxel size take precedence."""
+    `data.train` / `data.test` entries and point-sampler voxel size take precedence.
+    The subset stride belongs to the TRAINING split only: the released configs pass `load_frame_interval` to
+    `data.train` (vidar_1_8_nusc_1future.py:338-342) and not to `data.val` / `data.test` (:345-368), where the dataset's
+    default None applies (nuscenes_vidar_dataset_template.py:66-68) -- evaluation runs over the whole val split.  A
+    stride in test mode is an explicit choice: `test_stride` here (tools/test.py --eval-stride), or a `data.test` entry
+    of the loaded config file that names it."""
     d = dict(meta["data"])
     kw = dict(queue_length=meta["queue_length"], future_length=d["future_test"] if test_mode else meta["future_frames"],
-              rand_frame_interval=tuple(d["rand_frame_interval"]), load_frame_interval=d["load_frame_interval"],
+              rand_frame_interval=tuple(d["rand_frame_interval"]),
+              load_frame_interval=test_stride if test_mode else d["load_frame_interval"],
               voxel_size=(d["voxel_size"],) * 3, test_mode=test_mode,
               dataset="nuplan" if "OpenScene" in meta["name"] else "nuscenes")
     if d.get("img_scale"):
