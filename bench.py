@@ -243,7 +243,23 @@ def cpu_baseline_ops(threads):
     add("dvxlr.render[M=30000]", _once_or_twice(lambda: O.dvxlr_render(sig, origin, points, tindex)), "30000 rays, volume 16x200x200", dvr_impl)
     add("dvr.render_forward[M=30000]", _once_or_twice(lambda: O.render_forward(sig, origin, points, tindex, "train")), "same", dvr_impl)
     add("dvr.render[M=30000]", _once_or_twice(lambda: O.render(sig, origin, points, tindex, "l1")), "same", dvr_impl)
-    return dict(ops=rows, cores=threads)
+    # second column: the rows that scale with cores (OpenMP over rays; the MSDA formula over torch's intra-op pool) on
+    # ALL host cores (BASELINE.md section 3 asks for the box's cores; `threads` = 16 is where the torch rows stop scaling)
+    allc = os.cpu_count() or threads
+    if allc > threads:
+        by = {r["op"]: r for r in rows}
+        O.set_threads(allc)
+        for op, fn in (("dvxlr.render[M=30000]", lambda: O.dvxlr_render(sig, origin, points, tindex)),
+                       ("dvr.render_forward[M=30000]", lambda: O.render_forward(sig, origin, points, tindex, "train")),
+                       ("dvr.render[M=30000]", lambda: O.render(sig, origin, points, tindex, "l1"))):
+            by[op]["cpu_ms_all_cores"] = round(_once_or_twice(fn) * 1e3, 2)
+        O.set_threads(threads)
+        torch.set_num_threads(allc)
+        value, sh, lsi, loc, w = msda_operands(0, 6, fpn, 10000, P=8)
+        with torch.no_grad():
+            by["msda_fwd[L=4,P=8]"]["cpu_ms_all_cores"] = round(_once_or_twice(lambda: M.msda_grid_sample(value, sh, loc, w)) * 1e3, 2)
+        torch.set_num_threads(threads)
+    return dict(ops=rows, cores=threads, all_cores=allc)
 
 
 def cpu_baseline_subprocess(args, mode="ops"):
@@ -285,8 +301,11 @@ def cpu_baseline_record(args, gpu_ops, steps, kernel_rows):
             r["gpu_ms"] = gpu_kernels[r["op"]]
         if r.get("gpu_ms"):
             r["speedup"] = round(r["cpu_ms"] / r["gpu_ms"], 1)
+            if r.get("cpu_ms_all_cores"):
+                r["speedup_all_cores"] = round(r["cpu_ms_all_cores"] / r["gpu_ms"], 1)
     out = dict(value=(1e3 / bound_ms) if bound_ms > 0 else None, unit="samples/s", cores=rec["cores"], kind="port",
-               host_cores=os.cpu_count(), step_lower_bound_ms=round(bound_ms, 1), ops=rec["ops"],
+               host_cores=os.cpu_count(), all_cores_column=rec.get("all_cores"),
+               step_lower_bound_ms=round(bound_ms, 1), ops=rec["ops"],
                sample=(f"op-level, FULL size (BEV 200x200, 6 x 30825 px, 30000 rays): each SURVEY 8(a) op's oracle port "
                        f"timed once on {rec['cores']} threads (knn_cpu: 1), weighted by the GPU step's own launches per "
                        f"step; their sum ({bound_ms / 1e3:.1f} s) is a LOWER bound on the CPU step -- GEMMs, the image "

@@ -15,30 +15,34 @@ def _to(batch, dev):
                 img_feats=[f.to(dev) for f in batch["img_feats"]])
 
 
-def _batch_of(name, bs):
-    """bs samples of the small rig (bs = 1: test_plugin_cpu._small_batch)."""
+def _batch_of(name, bs, bev=24):
+    """bs samples of the small rig (bs = 1, bev 24: test_plugin_cpu._small_batch); bev 50 = BASELINE configs[0]'s
+    grid, with proportionally larger feature pyramids and ray sets."""
     from vidar_amd.configs import get_config
     from vidar_amd.synthetic import fpn_features, make_sample
-    if bs == 1:
+    if bs == 1 and bev == 24:
         return _small_batch(name)
-    cfg = get_config(name, bev_h=24, bev_w=24)
+    cfg = get_config(name, bev_h=bev, bev_w=bev)
     ms, gts = [], []
+    rays = 200 if bev == 24 else 800
+    shapes = [(15, 25), (8, 13), (4, 7), (2, 4)] if bev == 24 else [(29, 50), (15, 25), (8, 13), (4, 7)]
     for s_ in range(bs):
-        m, g = make_sample(s_, rays_per_frame=200, future_frames=cfg["future_frames"], num_cams=cfg["num_cams"])
+        m, g = make_sample(s_, rays_per_frame=rays, future_frames=cfg["future_frames"], num_cams=cfg["num_cams"])
         ms.append(m); gts.append(torch.from_numpy(g))
-    feats = fpn_features(0, 5, num_cams=cfg["num_cams"], shapes=[(15, 25), (8, 13), (4, 7), (2, 4)], bs=bs)
+    feats = fpn_features(0, 5, num_cams=cfg["num_cams"], shapes=shapes, bs=bs)
     return cfg, dict(img_metas=ms, gt_points=gts, img_feats=feats)
 
 
-@pytest.mark.parametrize("name,bs", [("vidar_1_8_nusc_1future", 1), ("vidar_1_8_nusc_3future", 1),
-                                     ("vidar_OpenScene_mini_full_3future", 1),      # 8 cameras (BASELINE config 4)
-                                     ("vidar_1_8_nusc_1future", 2)])                # per-GPU batch 2 (BASELINE config 3)
-def test_hip_step_matches_cpu_oracle_step(name, bs):
+@pytest.mark.parametrize("name,bs,bev", [("vidar_1_8_nusc_1future", 1, 24), ("vidar_1_8_nusc_3future", 1, 24),
+                                         ("vidar_OpenScene_mini_full_3future", 1, 24),   # 8 cameras (BASELINE config 4)
+                                         ("vidar_1_8_nusc_1future", 2, 24),              # per-GPU batch 2 (BASELINE config 3)
+                                         ("vidar_1_8_nusc_1future", 1, 50)])             # BASELINE configs[0]'s 50 x 50 BEV
+def test_hip_step_matches_cpu_oracle_step(name, bs, bev=24):
     from oracle import cpu_ops
     from vidar_amd import train as T
     from vidar_amd.plugin.dense_heads import ray_ops
     torch.manual_seed(0); np.random.seed(0)
-    cfg, batch = _batch_of(name, bs)
+    cfg, batch = _batch_of(name, bs, bev)
     model = T.build_model(cfg).eval()          # eval: dropout off, identical control flow
     for m in model.modules():
         if hasattr(m, "random_drop_prev_rate"):

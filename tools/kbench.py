@@ -321,6 +321,21 @@ def bench_gemm(which):
         line(f"conv dw  6x[{Co},{HW}]x[{HW},{Ci}] {tag}", fl6, nb / 4, **ms)
 
 
+def bench_gemm_pmc(which):
+    """a few launches of the representative GEMM shapes per mode, for the counter passes (tools/pmc_pass.sh)"""
+    from vidar_amd import gemm as G
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.rand(*s, device=dev, generator=g) * 2 - 1
+    x, w, b = rnd(184950, 256), rnd(256, 256) * 0.1, rnd(256)
+    wc, xc = rnd(1024, 256) * 0.05, rnd(24, 256, 5800)
+    for p in (G.F32, G.BF16X3):
+        for _ in range(3):
+            G.linear_forward(x, w, b, False, p)
+            G.conv_forward(wc, xc, precision=p)
+    torch.cuda.synchronize()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["dvr", "knn", "msda", "lr", "ray"]
     print(json.dumps({"device": torch.cuda.get_device_name(0)}))

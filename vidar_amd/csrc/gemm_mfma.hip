@@ -28,8 +28,7 @@
 // A lane's fragment is always the four units 8*s + 4*(lane>>5) + {0..3} of its row -- in bf16 mode they ARE the
 // eight consecutive k of one 32x32x16 operand, in fp32 mode they feed four 32x32x2 MFMAs whose two k slots
 // (lane halves) take units t and 4 + t; both operands use the same assignment, which is all a contraction needs.
-// The MFMA is issued with the operands swapped (rows := columns of B, columns := rows of A) so that a lane's
-// accumulator registers 4q..4q+3 are four CONSECUTIVE n of one row m: the epilogue stores 16 bytes per lane.
+// An accumulator register of a wave is two rows of 32 consecutive n: the epilogue's stores are whole 128-byte lines.
 //
 // Epilogue: y = relu?( acc * scale[m|n] + shift[m|n] + residual[m,n] ) -- the bias of F.linear, the frozen
 // BatchNorm + residual + ReLU that follows every 1x1 convolution of the ResNet bottlenecks
@@ -52,6 +51,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // 4-byte aligned: rows of H*W = 1450 floats
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, THREADS = 256;
 constexpr int UNITS = 16;                 // dwords of k per row per k-step
@@ -80,48 +80,90 @@ struct Staged {               // the registers a thread holds between its global
   f32x4 v[CH][2];
 };
 
-// K-major operand: element (row, k) at P[row * ld + k].  Row tid>>1 in both modes; bf16 mode (k-step 32): sixteen k from
-// (tid&1)*16 (64 contiguous bytes per lane, one pointer); fp32 mode (k-step 16): eight k from (tid&1)*8.
+// K-major operand: element (row, k) at P[row * ld + k].  The lanes of a wave instruction run along k first: LPR = BK/4
+// lanes x 16 bytes cover the whole k-step of one row (bf16 mode: 8 lanes = one 128-byte line; fp32 mode: 4 lanes = half
+// a line), 64/LPR rows per instruction, so every request is a full contiguous piece (one lane per row, or a pair of
+// lanes 64 bytes apart, made each dwordx4 touch 32 lines in 16-byte pieces: the kernel was bound by the texture
+// addresser, not by MFMA or HBM).  float4 number i of a thread: row 32*wave + i*(64/LPR) + lane/LPR, k (lane%LPR)*4.
+template <int PREC>
+struct KMap {
+  static constexpr int LPR = (PREC == PREC_BF16X3) ? 8 : 4;     // lanes per row
+  static constexpr int RPI = 64 / LPR;                          // rows per instruction
+  static constexpr int NI = 32 / RPI;                           // instructions (float4 per thread)
+};
+
+// Addressing of both loaders: buffer loads through a descriptor whose base is the workgroup's (uniform) tile origin at
+// the first k of its range, ONE 32-bit per-thread byte offset computed before the loop (voffset) and the uniform advance
+// of the k loop in a scalar register (soffset): no vector address arithmetic inside the loop.  The descriptor is built
+// from readfirstlane'd halves of the pointer so that the compiler can see it is uniform (no waterfall loops).
+// The host checks that the offsets fit 31 bits.
+typedef uint32_t raw4 __attribute__((__vector_size__(4 * sizeof(uint32_t))));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float ld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+template <int PREC>
+__device__ __forceinline__ uint32_t voff_kmajor(int64_t ld, int tid) {
+  using M = KMap<PREC>;
+  const int lane = tid & 63, wave = tid >> 6;
+  return (uint32_t)(((32 * wave + lane / M::LPR) * (uint32_t)ld + (lane % M::LPR) * 4) * 4);
+}
+
+// descriptor base = P + row0 * ld + kbeg ; krel = k0 - kbeg
 template <int PREC, bool FULL>
-__device__ __forceinline__ void load_kmajor(Staged<PREC>& s, const float* __restrict__ P, int64_t ld, int row0, int rows,
-                                            int k0, int kend, int tid) {
-  constexpr int NK = Staged<PREC>::CH * 8;
-  const int row = row0 + (tid >> 1);
-  const int k = k0 + (tid & 1) * NK;
-  const float* p = P + (int64_t)row * ld + k;
-  if (FULL || (row < rows && k + NK <= kend)) {
+__device__ __forceinline__ void load_kmajor(Staged<PREC>& s, __amdgpu_buffer_rsrc_t rs, int64_t ld, int row0, int rows,
+                                            int krel, int k0, int kend, int tid, uint32_t voff) {
+  using M = KMap<PREC>;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int k = k0 + (lane % M::LPR) * 4;
+  const int rbase = row0 + 32 * wave + lane / M::LPR;
 #pragma unroll
-    for (int c = 0; c < NK / 4; ++c) s.v[c >> 1][c & 1] = *(const f32x4u*)(p + 4 * c);
-  } else {
+  for (int i = 0; i < M::NI; ++i) {
+    const int row = rbase + i * M::RPI;
+    const uint32_t soff = (uint32_t)((i * M::RPI * (uint32_t)ld + krel) * 4);      // uniform
+    if (FULL || (row < rows && k + 4 <= kend)) {
+      s.v[i >> 1][i & 1] = ld16(rs, voff, soff);
+    } else {
 #pragma unroll
-    for (int j = 0; j < NK; ++j) s.v[j >> 3][(j >> 2) & 1][j & 3] = (row < rows && k + j < kend) ? p[j] : 0.0f;
+      for (int j = 0; j < 4; ++j) s.v[i >> 1][i & 1][j] = (row < rows && k + j < kend) ? ld4(rs, voff + 4 * j, soff) : 0.0f;
+    }
   }
 }
 
 // MN-major operand: element (k, col) at P[k * ld + col].  bf16 mode: item = tid + 256c, column quad item&31, k pair
 // item>>5 (two rows of four columns).  fp32 mode: items tid and tid + 256: column quad item&31, k = item>>5.
+template <int PREC>
+__device__ __forceinline__ uint32_t voff_mnmajor(int64_t ld, int tid) {
+  const int kr = (PREC == PREC_BF16X3) ? (tid >> 5) * 2 : (tid >> 5);
+  return (uint32_t)((kr * (uint32_t)ld + (tid & 31) * 4) * 4);
+}
+
+// descriptor base = P + kbeg * ld + col0 ; krel = k0 - kbeg
 template <int PREC, bool FULL>
-__device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, const float* __restrict__ P, int64_t ld, int col0, int cols,
-                                             int k0, int kend, int tid) {
+__device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, __amdgpu_buffer_rsrc_t rs, int64_t ld, int col0, int cols,
+                                             int krel, int k0, int kend, int tid, uint32_t voff) {
+  const int col = col0 + (tid & 31) * 4;
 #pragma unroll
   for (int i = 0; i < Staged<PREC>::CH * 2; ++i) {
-    int col, k;
-    if (PREC == PREC_BF16X3) {
-      const int item = tid + 256 * (i >> 1);
-      col = col0 + (item & 31) * 4;
-      k = k0 + (item >> 5) * 2 + (i & 1);
-    } else {
-      const int item = tid + 256 * i;
-      col = col0 + (item & 31) * 4;
-      k = k0 + (item >> 5);
-    }
-    const float* p = P + (int64_t)k * ld + col;
+    // uniform k of this load relative to the thread's own row: bf16 mode 16*(i>>1) + (i&1), fp32 mode 8*i
+    const int ku = (PREC == PREC_BF16X3) ? 16 * (i >> 1) + (i & 1) : 8 * i;
+    const int k = k0 + ku + ((PREC == PREC_BF16X3) ? (tid >> 5) * 2 : (tid >> 5));
+    const uint32_t soff = (uint32_t)(krel + ku) * (uint32_t)ld * 4u;                // uniform
     f32x4 v;
     if (FULL || (k < kend && col + 4 <= cols)) {
-      v = *(const f32x4u*)p;
+      v = ld16(rs, voff, soff);
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (k < kend && col + j < cols) ? p[j] : 0.0f;
+      for (int j = 0; j < 4; ++j) v[j] = (k < kend && col + j < cols) ? ld4(rs, voff + 4 * j, soff) : 0.0f;
     }
     s.v[i >> 1][i & 1] = v;
   }
@@ -140,23 +182,22 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 // LDS writes.  `img` = the operand's image (bf16 mode: hi at img, lo at img + IMG_DWORDS).
 template <int PREC>
 __device__ __forceinline__ void store_kmajor(const Staged<PREC>& s, uint32_t* img, int tid) {
-  const int r = tid >> 1, u = (tid & 1) * 8;
-  if (PREC == PREC_BF16X3) {
+  using M = KMap<PREC>;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r0 = 32 * wave + lane / M::LPR, kq = lane % M::LPR;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {          // chunk c: k 8c .. 8c+7 of the lane's sixteen -> units u + 4c .. +3
-      u32x4 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t h, l;
-        split2(s.v[c][j >> 1][(j & 1) * 2], s.v[c][j >> 1][(j & 1) * 2 + 1], h, l);
-        hi[j] = h; lo[j] = l;
-      }
-      *(u32x4*)(img + r * KM_STRIDE + u + 4 * c) = hi;
-      *(u32x4*)(img + IMG_DWORDS + r * KM_STRIDE + u + 4 * c) = lo;
+  for (int i = 0; i < M::NI; ++i) {
+    const int r = r0 + i * M::RPI;
+    const f32x4 v = s.v[i >> 1][i & 1];
+    if (PREC == PREC_BF16X3) {             // four k -> two units (k pairs) of hi and of lo
+      uint32_t h0, l0, h1, l1;
+      split2(v[0], v[1], h0, l0);
+      split2(v[2], v[3], h1, l1);
+      *(u32x2*)(img + r * KM_STRIDE + 2 * kq) = u32x2{h0, h1};
+      *(u32x2*)(img + IMG_DWORDS + r * KM_STRIDE + 2 * kq) = u32x2{l0, l1};
+    } else {                               // (stored as dwords, the type every fragment read uses)
+      *(u32x4*)(img + r * KM_STRIDE + 4 * kq) = __builtin_bit_cast(u32x4, v);
     }
-  } else {
-    *(f32x4*)(img + r * KM_STRIDE + u) = s.v[0][0];
-    *(f32x4*)(img + r * KM_STRIDE + u + 4) = s.v[0][1];
   }
 }
 
@@ -181,7 +222,7 @@ __device__ __forceinline__ void store_mnmajor(const Staged<PREC>& s, uint32_t* i
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int item = tid + 256 * i;
-      *(f32x4*)(img + (item >> 5) * MN_STRIDE + (item & 31) * 4) = s.v[0][i];
+      *(u32x4*)(img + (item >> 5) * MN_STRIDE + (item & 31) * 4) = __builtin_bit_cast(u32x4, s.v[0][i]);
     }
   }
 }
@@ -207,11 +248,16 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], const float* __res
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
   Staged<PREC> sa, sb;
+  const uint32_t voa = ALAY == LAY_K ? voff_kmajor<PREC>(g.lda, tid) : voff_mnmajor<PREC>(g.lda, tid);
+  const uint32_t vob = BLAY == LAY_K ? voff_kmajor<PREC>(g.ldb, tid) : voff_mnmajor<PREC>(g.ldb, tid);
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(ALAY == LAY_K ? A + (int64_t)m0 * g.lda + kbeg : A + (int64_t)kbeg * g.lda + m0);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(BLAY == LAY_K ? B + (int64_t)n0 * g.ldb + kbeg : B + (int64_t)kbeg * g.ldb + n0);
   auto fetch = [&](int k0) {
-    if (ALAY == LAY_K) load_kmajor<PREC, FULL>(sa, A, g.lda, m0, g.M, k0, kend, tid);
-    else load_mnmajor<PREC, FULL>(sa, A, g.lda, m0, g.M, k0, kend, tid);
-    if (BLAY == LAY_K) load_kmajor<PREC, FULL>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
-    else load_mnmajor<PREC, FULL>(sb, B, g.ldb, n0, g.N, k0, kend, tid);
+    const int krel = k0 - kbeg;
+    if (ALAY == LAY_K) load_kmajor<PREC, FULL>(sa, rsA, g.lda, m0, g.M, krel, k0, kend, tid, voa);
+    else load_mnmajor<PREC, FULL>(sa, rsA, g.lda, m0, g.M, krel, k0, kend, tid, voa);
+    if (BLAY == LAY_K) load_kmajor<PREC, FULL>(sb, rsB, g.ldb, n0, g.N, krel, k0, kend, tid, vob);
+    else load_mnmajor<PREC, FULL>(sb, rsB, g.ldb, n0, g.N, krel, k0, kend, tid, vob);
   };
   if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -236,14 +282,14 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], const float* __res
           if (PREC == PREC_BF16X3) {
             const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[i][0]), al = __builtin_bit_cast(bf16x8, fa[i][IMGS - 1]);
             const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[j][0]), bl = __builtin_bit_cast(bf16x8, fb[j][IMGS - 1]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
           } else {
+            const f32x4 bf = __builtin_bit_cast(f32x4, fb[j][0]), af = __builtin_bit_cast(f32x4, fa[i][0]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, fb[j][0][u]),
-                                                               __builtin_bit_cast(float, fa[i][0][u]), acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u], acc[i][j], 0, 0, 0);
           }
         }
     }
@@ -268,11 +314,12 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
     const int q = nwg >> 3, r = nwg & 7, x = id & 7;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
   }
-  const int z = id / per_z;
+  // (integer division runs on the vector ALU: pin the workgroup-uniform results back into scalar registers)
+  const int z = __builtin_amdgcn_readfirstlane(id / per_z);
   const int t = id - z * per_z;
-  const int tm = g.m_fastest ? t % g.tiles_m : t / g.tiles_n;
-  const int tn = g.m_fastest ? t / g.tiles_m : t % g.tiles_n;
-  const int batch = z / g.splits, split = z - batch * g.splits;
+  const int tm = __builtin_amdgcn_readfirstlane(g.m_fastest ? t % g.tiles_m : t / g.tiles_n);
+  const int tn = __builtin_amdgcn_readfirstlane(g.m_fastest ? t / g.tiles_m : t % g.tiles_n);
+  const int batch = __builtin_amdgcn_readfirstlane(z / g.splits), split = z - batch * g.splits;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = split * g.k_chunk;
   const int kend = min(g.K, kbeg + g.k_chunk);
@@ -292,7 +339,8 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   if (full) mainloop<PREC, ALAY, BLAY, true>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, threadIdx.x);
   else mainloop<PREC, ALAY, BLAY, false>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, threadIdx.x);
 
-  // ---- epilogue: lane holds, per (i, j, q): row m = m0 + wm + 32i + l31, columns n = n0 + wn + 32j + 8q + 4h + {0..3}
+  // ---- epilogue: accumulator register r of tile (i, j) is row m = m0 + wm + 32i + (r&3) + 8(r>>2) + 4h, column
+  // n = n0 + wn + 32j + (lane&31): one store instruction writes two rows of 32 consecutive floats (two full 128-byte lines)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
@@ -301,52 +349,34 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   else { C = g.C + (int64_t)batch * g.sC; ldc = g.ldc; }
   const bool epi = !g.slabs;
   const float* R = (epi && g.residual) ? g.residual + (int64_t)batch * g.sR : nullptr;
+  const bool by_n = epi && g.vec_axis == 0, by_m = epi && g.vec_axis == 1;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm + 32 * i + l31;
-    if (m >= g.M) continue;
-    float sm = 1.0f, bm = 0.0f;
-    if (epi && g.vec_axis == 1) {
-      if (g.scale) sm = g.scale[m];
-      if (g.shift) bm = g.shift[m];
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn + 32 * j + l31;
+    if (n >= g.N) continue;
+    float sn = 1.0f, bn = 0.0f;
+    if (by_n) {
+      if (g.scale) sn = g.scale[n];
+      if (g.shift) bn = g.shift[n];
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn + 32 * j + 8 * q + 4 * h;
-        if (n >= g.N) continue;
-        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        const bool full = n + 4 <= g.N;
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= g.M) continue;
+        float y = acc[i][j][r];
         if (epi) {
-          f32x4 sc = {sm, sm, sm, sm}, sh = {bm, bm, bm, bm}, rs = {0.f, 0.f, 0.f, 0.f};
-          if (g.vec_axis == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              if (n + e < g.N) {
-                if (g.scale) sc[e] = g.scale[n + e];
-                if (g.shift) sh[e] = g.shift[n + e];
-              }
-            }
+          float sc = sn, sh = bn;
+          if (by_m) {
+            if (g.scale) sc = g.scale[m];
+            if (g.shift) sh = g.shift[m];
           }
-          if (R) {
-            const float* rp = R + (int64_t)m * g.ldr + n;
-            if (full) rs = *(const f32x4u*)rp;
-            else
-#pragma unroll
-              for (int e = 0; e < 4; ++e) if (n + e < g.N) rs[e] = rp[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float y = v[e] * sc[e] + sh[e] + rs[e];
-            v[e] = (g.relu && !(y > 0.0f)) ? 0.0f : y;
-          }
+          y = y * sc + sh;
+          if (R) y += R[(int64_t)m * g.ldr + n];
+          if (g.relu && !(y > 0.0f)) y = 0.0f;
         }
-        float* cp = C + (int64_t)m * ldc + n;
-        if (full) *(f32x4u*)cp = v;
-        else
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (n + e < g.N) cp[e] = v[e];
+        C[(int64_t)m * ldc + n] = y;
       }
   }
 }
@@ -412,6 +442,10 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   if (vec_axis != 0 && vec_axis != 1) return VIDAR_ERR_BAD_ARG;
   if (lda < (a_layout == LAY_K ? K : M) || ldb < (b_layout == LAY_K ? K : N) || ldc < N) return VIDAR_ERR_BAD_ARG;
   if (residual != nullptr && ldr < N) return VIDAR_ERR_BAD_ARG;
+  // 31-bit byte offsets inside a workgroup's view of an operand: 128 rows x ld (K-major), k range x ld (MN-major)
+  if (lda >= (1 << 22) || ldb >= (1 << 22)) return VIDAR_ERR_BAD_ARG;
+  if ((a_layout == LAY_MN && (int64_t)K * lda >= (1LL << 29)) || (b_layout == LAY_MN && (int64_t)K * ldb >= (1LL << 29)))
+    return VIDAR_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int bk = precision == PREC_BF16X3 ? 32 : 16;
   GemmArgs g;
