@@ -48,10 +48,14 @@ def test_layouts_and_ragged_shapes(precision, a_layout, b_layout, M, N, K):
     A = a_store if a_layout == 0 else a_store.t()
     B = b_store.t() if b_layout == 0 else b_store
     ref = A.double() @ B.double()
-    C = torch.full((M, N), float("nan"), device=DEV)
-    G.gemm_raw(a_store, a_store.stride(0), a_layout, b_store, b_store.stride(0), b_layout, C, N, M, N, K,
+    # C is a window of a larger NaN-filled buffer: nothing outside the window may be written (rows past M are cut by
+    # the store descriptor's range check, columns past N by the kernel's own test)
+    big = torch.full((M + 40, N + 8), float("nan"), device=DEV)
+    C = big[:M, :N]
+    G.gemm_raw(a_store, a_store.stride(0), a_layout, b_store, b_store.stride(0), b_layout, C, big.stride(0), M, N, K,
                precision=precision)
     assert torch.isfinite(C).all()
+    assert torch.isnan(big[M:]).all() and torch.isnan(big[:, N:]).all(), "wrote outside the [M, N] window"
     # fp32 mode: K <= 263 products of |x| <= 1 -> 2e-6 of the largest entry; bf16x3: 3 * 2^-16 per product -> 1e-4 bound
     tol = 2e-6 if precision == G.F32 else 6e-5
     assert normwise(C, ref) <= tol, normwise(C, ref)
@@ -80,9 +84,11 @@ def test_epilogue_scale_shift_residual_relu(precision, vec_axis):
     acc = A.double() @ Bs.double().t()
     bc = (lambda v: v.double()[None, :]) if vec_axis == 0 else (lambda v: v.double()[:, None])
     ref = torch.relu(acc * bc(scale) + bc(shift) + res.double())
-    C = torch.empty(M, N, device=DEV)
+    big = torch.full((M + 3, N), float("nan"), device=DEV)     # the residual's descriptor ends at row M: no read past it
+    C = big[:M]
     G.gemm_raw(A, K, 0, Bs, K, 0, C, N, M, N, K, scale=scale, shift=shift, vec_axis=vec_axis, residual=res, ldr=N,
                relu=True, precision=precision)
+    assert torch.isnan(big[M:]).all()
     assert normwise(C, ref) <= (2e-6 if precision == G.F32 else 6e-5)
     assert float((C == 0).float().mean()) > 0.2 and float(C.min()) >= 0.0          # the ReLU was applied
 

@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vidar_hip.h"
 #include "vidar_common.h"
@@ -71,6 +72,7 @@ struct GemmArgs {
   const float* residual; int64_t ldr, sR;
   int relu;
   int tiles_m, tiles_n, m_fastest;
+  int ablate;      // diagnosis only (VIDAR_GEMM_ABLATE): bit 0 no global loads after the first, 1 no MFMA, 2 no stores, 3 no LDS staging
 };
 
 // ---- staging: 16 (fp32 mode: 8) floats per operand per thread ----------------------------------------------------
@@ -99,10 +101,11 @@ struct KMap {
 // The host checks that the offsets fit 31 bits.
 typedef uint32_t raw4 __attribute__((__vector_size__(4 * sizeof(uint32_t))));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, int64_t bytes = 0x7fffffff) {
   const uint64_t a = (uint64_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+  const int32_t n = __builtin_amdgcn_readfirstlane((int32_t)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
 }
 __device__ __forceinline__ f32x4 ld16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
@@ -261,10 +264,13 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], const float* __res
   };
   if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
-    if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
+    if (!(g.ablate & 8)) {
+      if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
+      if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
+    }
     __syncthreads();
-    if (k0 + BK < kend) fetch(k0 + BK);          // in flight under the MFMAs below
+    if (k0 + BK < kend && !(g.ablate & 1)) fetch(k0 + BK);          // in flight under the MFMAs below
+    if (!(g.ablate & 2))
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u32x4 fa[2][IMGS], fb[2][IMGS];
@@ -340,7 +346,10 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   else mainloop<PREC, ALAY, BLAY, false>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, threadIdx.x);
 
   // ---- epilogue: accumulator register r of tile (i, j) is row m = m0 + wm + 32i + (r&3) + 8(r>>2) + 4h, column
-  // n = n0 + wn + 32j + (lane&31): one store instruction writes two rows of 32 consecutive floats (two full 128-byte lines)
+  // n = n0 + wn + 32j + (lane&31): one store instruction writes two rows of 32 consecutive floats (two full 128-byte
+  // lines).  Buffer addressing again: the lane's part of the offset is ONE register, the register's part is scalar;
+  // the descriptors end at the matrix' last element, so rows past M are dropped (stores) / read as 0 (loads) by the
+  // hardware's range check and only the column test n < N remains, once per column tile.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
@@ -348,36 +357,51 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   if (g.slabs) { C = g.C + (int64_t)z * g.M * g.N; ldc = g.N; }
   else { C = g.C + (int64_t)batch * g.sC; ldc = g.ldc; }
   const bool epi = !g.slabs;
-  const float* R = (epi && g.residual) ? g.residual + (int64_t)batch * g.sR : nullptr;
   const bool by_n = epi && g.vec_axis == 0, by_m = epi && g.vec_axis == 1;
+  const int rows_left = g.M - m0, cols_left = g.N - n0;                      // >= 1
+  const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C + (int64_t)m0 * ldc + n0, ((int64_t)(rows_left - 1) * ldc + cols_left) * 4);
+  const uint32_t voC = (uint32_t)(((wm + 4 * h) * (uint32_t)ldc + wn + l31) * 4);
+  const bool has_res = epi && g.residual != nullptr;
+  const float* Rp = has_res ? g.residual + (int64_t)batch * g.sR + (int64_t)m0 * g.ldr + n0 : C;
+  const __amdgpu_buffer_rsrc_t rsR = make_rsrc(Rp, has_res ? ((int64_t)(rows_left - 1) * g.ldr + cols_left) * 4 : 0);
+  const uint32_t voR = (uint32_t)(((wm + 4 * h) * (uint32_t)g.ldr + wn + l31) * 4);
+  const bool m_scale = by_m && g.scale != nullptr, m_shift = by_m && g.shift != nullptr;
+  const __amdgpu_buffer_rsrc_t rsS = make_rsrc(m_scale ? g.scale + m0 : C, m_scale ? (int64_t)rows_left * 4 : 0);
+  const __amdgpu_buffer_rsrc_t rsH = make_rsrc(m_shift ? g.shift + m0 : C, m_shift ? (int64_t)rows_left * 4 : 0);
+  const uint32_t voM = (uint32_t)((wm + 4 * h) * 4);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn + 32 * j + l31;
     if (n >= g.N) continue;
     float sn = 1.0f, bn = 0.0f;
-    if (by_n) {
-      if (g.scale) sn = g.scale[n];
-      if (g.shift) bn = g.shift[n];
-    }
+    if (by_n && g.scale) sn = g.scale[n];
+    if (by_n && g.shift) bn = g.shift[n];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= g.M) continue;
-        float y = acc[i][j][r];
-        if (epi) {
-          float sc = sn, sh = bn;
-          if (by_m) {
-            if (g.scale) sc = g.scale[m];
-            if (g.shift) sh = g.shift[m];
-          }
-          y = y * sc + sh;
-          if (R) y += R[(int64_t)m * g.ldr + n];
-          if (g.relu && !(y > 0.0f)) y = 0.0f;
+      for (int r0 = 0; r0 < 16; r0 += 8) {               // groups of 8 registers: their loads are issued together
+        float sc[8], sh[8], rs[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int row = 32 * i + (r & 3) + 8 * ((r0 + r) >> 2);         // uniform part of the row inside the wave's tile
+          sc[r] = m_scale ? ld4(rsS, voM, (uint32_t)(row * 4)) : sn;
+          sh[r] = m_shift ? ld4(rsH, voM, (uint32_t)(row * 4)) : bn;
+          rs[r] = has_res ? ld4(rsR, voR, (uint32_t)((row * (uint32_t)g.ldr + 32 * j) * 4)) : 0.0f;
         }
-        C[(int64_t)m * ldc + n] = y;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int row = 32 * i + (r & 3) + 8 * ((r0 + r) >> 2);
+          float y = acc[i][j][r0 + r];
+          if (epi) {
+            y = y * sc[r] + sh[r] + rs[r];
+            if (g.relu && !(y > 0.0f)) y = 0.0f;
+          }
+          if (!(g.ablate & 4))
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC, voC,
+                                                  (uint32_t)((row * (uint32_t)ldc + 32 * j) * 4), 0);
+        }
       }
+    }
   }
 }
 
@@ -441,7 +465,8 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   if (precision != PREC_F32 && precision != PREC_BF16X3) return VIDAR_ERR_BAD_ARG;
   if (vec_axis != 0 && vec_axis != 1) return VIDAR_ERR_BAD_ARG;
   if (lda < (a_layout == LAY_K ? K : M) || ldb < (b_layout == LAY_K ? K : N) || ldc < N) return VIDAR_ERR_BAD_ARG;
-  if (residual != nullptr && ldr < N) return VIDAR_ERR_BAD_ARG;
+  if (residual != nullptr && (ldr < N || ldr >= (1 << 22))) return VIDAR_ERR_BAD_ARG;
+  if (ldc >= (1 << 22)) return VIDAR_ERR_BAD_ARG;
   // 31-bit byte offsets inside a workgroup's view of an operand: 128 rows x ld (K-major), k range x ld (MN-major)
   if (lda >= (1 << 22) || ldb >= (1 << 22)) return VIDAR_ERR_BAD_ARG;
   if ((a_layout == LAY_MN && (int64_t)K * lda >= (1LL << 29)) || (b_layout == LAY_MN && (int64_t)K * ldb >= (1LL << 29)))
@@ -454,6 +479,7 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   g.M = M; g.N = N; g.K = K;
   g.scale = scale; g.shift = shift; g.vec_axis = vec_axis; g.residual = residual; g.ldr = ldr; g.sR = strideR;
   g.relu = relu;
+  { const char* e = getenv("VIDAR_GEMM_ABLATE"); g.ablate = e ? atoi(e) : 0; }
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.m_fastest = M < N;
   g.splits = reduce ? pick_splits(M, N, K, batch, bk) : 1;
