@@ -72,7 +72,8 @@ struct GemmArgs {
   const float* residual; int64_t ldr, sR;
   int relu;
   int tiles_m, tiles_n, m_fastest;
-  int ablate;      // diagnosis only (VIDAR_GEMM_ABLATE): bit 0 no global loads after the first, 1 no MFMA, 2 no stores, 3 no LDS staging
+  int total;       // tiles_m * tiles_n * (batch * splits)
+  int ablate;      // diagnosis only (VIDAR_GEMM_ABLATE): bit 0 no global loads after a tile's first, 1 no MFMA, 2 no stores, 3 no LDS staging, 4 no cross-tile prefetch
 };
 
 // ---- staging: 16 (fp32 mode: 8) floats per operand per thread ----------------------------------------------------
@@ -121,24 +122,23 @@ __device__ __forceinline__ uint32_t voff_kmajor(int64_t ld, int tid) {
   return (uint32_t)(((32 * wave + lane / M::LPR) * (uint32_t)ld + (lane % M::LPR) * 4) * 4);
 }
 
-// descriptor base = P + row0 * ld + kbeg ; krel = k0 - kbeg
-template <int PREC, bool FULL>
-__device__ __forceinline__ void load_kmajor(Staged<PREC>& s, __amdgpu_buffer_rsrc_t rs, int64_t ld, int row0, int rows,
-                                            int krel, int k0, int kend, int tid, uint32_t voff) {
+// descriptor base = P + row0 * ld + kbeg, ending at the matrix' last element ; krel = k0 - kbeg.
+// No per-lane bounds checks: rows past the matrix only feed output rows that are never stored (and read as 0 past the
+// descriptor's end); a k-step that reaches past K reads the start of the next row, so its lanes are masked -- `tail` is
+// workgroup-uniform and true for at most the last k-step of a product whose K is not a multiple of the k-step.
+template <int PREC>
+__device__ __forceinline__ void load_kmajor(Staged<PREC>& s, __amdgpu_buffer_rsrc_t rs, int64_t ld, int krel, int k0, int kend,
+                                            bool tail, int tid, uint32_t voff) {
   using M = KMap<PREC>;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int k = k0 + (lane % M::LPR) * 4;
-  const int rbase = row0 + 32 * wave + lane / M::LPR;
 #pragma unroll
-  for (int i = 0; i < M::NI; ++i) {
-    const int row = rbase + i * M::RPI;
-    const uint32_t soff = (uint32_t)((i * M::RPI * (uint32_t)ld + krel) * 4);      // uniform
-    if (FULL || (row < rows && k + 4 <= kend)) {
-      s.v[i >> 1][i & 1] = ld16(rs, voff, soff);
-    } else {
+  for (int i = 0; i < M::NI; ++i)
+    s.v[i >> 1][i & 1] = ld16(rs, voff, (uint32_t)((i * M::RPI * (uint32_t)ld + krel) * 4));
+  if (tail) {
+    const int k = k0 + ((tid & 63) % M::LPR) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s.v[i >> 1][i & 1][j] = (row < rows && k + j < kend) ? ld4(rs, voff + 4 * j, soff) : 0.0f;
-    }
+    for (int i = 0; i < M::NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s.v[i >> 1][i & 1][j] = (k + j < kend) ? s.v[i >> 1][i & 1][j] : 0.0f;
   }
 }
 
@@ -150,25 +150,15 @@ __device__ __forceinline__ uint32_t voff_mnmajor(int64_t ld, int tid) {
   return (uint32_t)((kr * (uint32_t)ld + (tid & 31) * 4) * 4);
 }
 
-// descriptor base = P + kbeg * ld + col0 ; krel = k0 - kbeg
-template <int PREC, bool FULL>
-__device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, __amdgpu_buffer_rsrc_t rs, int64_t ld, int col0, int cols,
-                                             int krel, int k0, int kend, int tid, uint32_t voff) {
-  const int col = col0 + (tid & 31) * 4;
+// descriptor base = P + kbeg * ld + col0, ending at the matrix' last element ; krel = k0 - kbeg.  Rows k >= K lie past the
+// descriptor's end and read as 0 (the k tail needs no mask); columns past the matrix only feed outputs that are never stored.
+template <int PREC>
+__device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, __amdgpu_buffer_rsrc_t rs, int64_t ld, int krel, uint32_t voff) {
 #pragma unroll
   for (int i = 0; i < Staged<PREC>::CH * 2; ++i) {
     // uniform k of this load relative to the thread's own row: bf16 mode 16*(i>>1) + (i&1), fp32 mode 8*i
     const int ku = (PREC == PREC_BF16X3) ? 16 * (i >> 1) + (i & 1) : 8 * i;
-    const int k = k0 + ku + ((PREC == PREC_BF16X3) ? (tid >> 5) * 2 : (tid >> 5));
-    const uint32_t soff = (uint32_t)(krel + ku) * (uint32_t)ld * 4u;                // uniform
-    f32x4 v;
-    if (FULL || (k < kend && col + 4 <= cols)) {
-      v = ld16(rs, voff, soff);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (k < kend && col + j < cols) ? ld4(rs, voff + 4 * j, soff) : 0.0f;
-    }
-    s.v[i >> 1][i & 1] = v;
+    s.v[i >> 1][i & 1] = ld16(rs, voff, (uint32_t)(krel + ku) * (uint32_t)ld * 4u);
   }
 }
 
@@ -241,35 +231,74 @@ __device__ __forceinline__ u32x4 frag(const uint32_t* img, int row, int s, int h
   return f;
 }
 
-template <int PREC, int ALAY, int BLAY, bool FULL>
-__device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], const float* __restrict__ A, const float* __restrict__ B,
-                                         const GemmArgs& g, uint32_t* imgA, uint32_t* imgB, int m0, int n0, int kbeg,
-                                         int kend, int tid) {
+// one output tile of one workgroup: everything here is workgroup-uniform (scalar registers)
+struct Tile {
+  int z, batch, m0, n0, kbeg, kend;
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+};
+
+template <int PREC, int ALAY, int BLAY>
+__device__ __forceinline__ Tile decode_tile(const GemmArgs& g, int t) {
+  // tile order.  Consecutive ids of one XCD (t & 7 = blockIdx & 7: the persistent grid is a multiple of 8) walk the
+  // shorter tile axis first, so the big operand's strip is fetched from HBM once and re-read from that XCD's L2.
+  const int per_z = g.tiles_m * g.tiles_n;
+  int id;
+  {
+    const int q = g.total >> 3, r = g.total & 7, x = t & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (t >> 3);
+  }
+  Tile T;
+  // (integer division runs on the vector ALU: pin the workgroup-uniform results back into scalar registers)
+  T.z = __builtin_amdgcn_readfirstlane(id / per_z);
+  const int tt = id - T.z * per_z;
+  const int tm = __builtin_amdgcn_readfirstlane(g.m_fastest ? tt % g.tiles_m : tt / g.tiles_n);
+  const int tn = __builtin_amdgcn_readfirstlane(g.m_fastest ? tt / g.tiles_m : tt % g.tiles_n);
+  T.batch = __builtin_amdgcn_readfirstlane(T.z / g.splits);
+  const int split = T.z - T.batch * g.splits;
+  T.m0 = tm * BM; T.n0 = tn * BN;
+  T.kbeg = split * g.k_chunk;
+  T.kend = min(g.K, T.kbeg + g.k_chunk);
+  const float* A = g.A + (int64_t)T.batch * g.sA;
+  const float* B = g.B + (int64_t)T.batch * g.sB;
+  // descriptors: from the tile's first element to the operand's last one (bytes)
+  const int64_t kleft = g.K - T.kbeg;
+  T.rsA = ALAY == LAY_K ? make_rsrc(A + (int64_t)T.m0 * g.lda + T.kbeg, ((int64_t)(g.M - 1 - T.m0) * g.lda + kleft) * 4)
+                        : make_rsrc(A + (int64_t)T.kbeg * g.lda + T.m0, ((kleft - 1) * g.lda + (g.M - T.m0)) * 4);
+  T.rsB = BLAY == LAY_K ? make_rsrc(B + (int64_t)T.n0 * g.ldb + T.kbeg, ((int64_t)(g.N - 1 - T.n0) * g.ldb + kleft) * 4)
+                        : make_rsrc(B + (int64_t)T.kbeg * g.ldb + T.n0, ((kleft - 1) * g.ldb + (g.N - T.n0)) * 4);
+  return T;
+}
+
+// global loads of the k-step starting at k0 of tile T into the staging registers
+template <int PREC, int ALAY, int BLAY>
+__device__ __forceinline__ void fetch(Staged<PREC>& sa, Staged<PREC>& sb, const GemmArgs& g, const Tile& T, int k0, int tid,
+                                      uint32_t voa, uint32_t vob) {
+  constexpr int BK = (PREC == PREC_BF16X3) ? 32 : 16;
+  const int krel = k0 - T.kbeg;
+  const bool tail = k0 + BK > T.kend;
+  if (ALAY == LAY_K) load_kmajor<PREC>(sa, T.rsA, g.lda, krel, k0, T.kend, tail, tid, voa);
+  else load_mnmajor<PREC>(sa, T.rsA, g.lda, krel, voa);
+  if (BLAY == LAY_K) load_kmajor<PREC>(sb, T.rsB, g.ldb, krel, k0, T.kend, tail, tid, vob);
+  else load_mnmajor<PREC>(sb, T.rsB, g.ldb, krel, vob);
+}
+
+// the k loop of one tile.  On entry the staging registers hold (or are about to receive) the tile's first k-step.
+template <int PREC, int ALAY, int BLAY>
+__device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, Staged<PREC>& sb, const GemmArgs& g,
+                                         const Tile& T, uint32_t* imgA, uint32_t* imgB, int tid, uint32_t voa, uint32_t vob) {
   constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
   constexpr int BK = (PREC == PREC_BF16X3) ? 32 : 16;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
-  Staged<PREC> sa, sb;
-  const uint32_t voa = ALAY == LAY_K ? voff_kmajor<PREC>(g.lda, tid) : voff_mnmajor<PREC>(g.lda, tid);
-  const uint32_t vob = BLAY == LAY_K ? voff_kmajor<PREC>(g.ldb, tid) : voff_mnmajor<PREC>(g.ldb, tid);
-  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(ALAY == LAY_K ? A + (int64_t)m0 * g.lda + kbeg : A + (int64_t)kbeg * g.lda + m0);
-  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(BLAY == LAY_K ? B + (int64_t)n0 * g.ldb + kbeg : B + (int64_t)kbeg * g.ldb + n0);
-  auto fetch = [&](int k0) {
-    const int krel = k0 - kbeg;
-    if (ALAY == LAY_K) load_kmajor<PREC, FULL>(sa, rsA, g.lda, m0, g.M, krel, k0, kend, tid, voa);
-    else load_mnmajor<PREC, FULL>(sa, rsA, g.lda, m0, g.M, krel, k0, kend, tid, voa);
-    if (BLAY == LAY_K) load_kmajor<PREC, FULL>(sb, rsB, g.ldb, n0, g.N, krel, k0, kend, tid, vob);
-    else load_mnmajor<PREC, FULL>(sb, rsB, g.ldb, n0, g.N, krel, k0, kend, tid, vob);
-  };
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  for (int k0 = T.kbeg; k0 < T.kend; k0 += BK) {
     if (!(g.ablate & 8)) {
       if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
       if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
     }
     __syncthreads();
-    if (k0 + BK < kend && !(g.ablate & 1)) fetch(k0 + BK);          // in flight under the MFMAs below
+    if (k0 + BK < T.kend && !(g.ablate & 1))
+      fetch<PREC, ALAY, BLAY>(sa, sb, g, T, k0 + BK, tid, voa, vob);          // in flight under the MFMAs below
     if (!(g.ablate & 2))
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -292,6 +321,7 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], const float* __res
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
           } else {
+            // (`__builtin_bit_cast(float, vec[u])` on a vector ELEMENT folds every u to element 0 on ROCm 7.2: cast the vector)
             const f32x4 bf = __builtin_bit_cast(f32x4, fb[j][0]), af = __builtin_bit_cast(f32x4, fa[i][0]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -303,66 +333,26 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], const float* __res
   }
 }
 
-template <int PREC, int ALAY, int BLAY>
-__global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
-  constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
-  constexpr int BK = (PREC == PREC_BF16X3) ? 32 : 16;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * IMGS * IMG_DWORDS];
-  uint32_t* imgA = lds;
-  uint32_t* imgB = lds + IMGS * IMG_DWORDS;
-
-  // workgroup -> tile.  Consecutive ids (after the XCD remap: one XCD's L2) walk the shorter tile axis first, so the
-  // big operand's strip is fetched from HBM once and re-read from L2 by the tiles that share it.
-  const int per_z = g.tiles_m * g.tiles_n;
-  const int nwg = per_z * (int)gridDim.y;
-  int id = blockIdx.x + blockIdx.y * per_z;
-  {
-    const int q = nwg >> 3, r = nwg & 7, x = id & 7;
-    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
-  }
-  // (integer division runs on the vector ALU: pin the workgroup-uniform results back into scalar registers)
-  const int z = __builtin_amdgcn_readfirstlane(id / per_z);
-  const int t = id - z * per_z;
-  const int tm = __builtin_amdgcn_readfirstlane(g.m_fastest ? t % g.tiles_m : t / g.tiles_n);
-  const int tn = __builtin_amdgcn_readfirstlane(g.m_fastest ? t / g.tiles_m : t % g.tiles_n);
-  const int batch = __builtin_amdgcn_readfirstlane(z / g.splits), split = z - batch * g.splits;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = split * g.k_chunk;
-  const int kend = min(g.K, kbeg + g.k_chunk);
-
-  const float* A = g.A + (int64_t)batch * g.sA;
-  const float* B = g.B + (int64_t)batch * g.sB;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  // interior workgroups (all of them for the hot shapes) run the loop without a single per-lane bounds check
-  const bool full = m0 + BM <= g.M && n0 + BN <= g.N && ((kend - kbeg) % BK) == 0;
-  if (full) mainloop<PREC, ALAY, BLAY, true>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, threadIdx.x);
-  else mainloop<PREC, ALAY, BLAY, false>(acc, A, B, g, imgA, imgB, m0, n0, kbeg, kend, threadIdx.x);
-
-  // ---- epilogue: accumulator register r of tile (i, j) is row m = m0 + wm + 32i + (r&3) + 8(r>>2) + 4h, column
-  // n = n0 + wn + 32j + (lane&31): one store instruction writes two rows of 32 consecutive floats (two full 128-byte
-  // lines).  Buffer addressing again: the lane's part of the offset is ONE register, the register's part is scalar;
-  // the descriptors end at the matrix' last element, so rows past M are dropped (stores) / read as 0 (loads) by the
-  // hardware's range check and only the column test n < N remains, once per column tile.
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// epilogue of one tile: accumulator register r of MFMA tile (i, j) is row m = m0 + wm + 32i + (r&3) + 8(r>>2) + 4h, column
+// n = n0 + wn + 32j + (lane&31): one store instruction writes two rows of 32 consecutive floats (two full 128-byte
+// lines).  Buffer addressing again: the lane's part of the offset is ONE register, the register's part is scalar;
+// the descriptors end at the matrix' last element, so rows past M are dropped (stores) / read as 0 (loads) by the
+// hardware's range check and only the column test n < N remains, once per column tile.
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, const Tile& T, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
+  const int m0 = T.m0, n0 = T.n0;
   float* C; int64_t ldc;
-  if (g.slabs) { C = g.C + (int64_t)z * g.M * g.N; ldc = g.N; }
-  else { C = g.C + (int64_t)batch * g.sC; ldc = g.ldc; }
+  if (g.slabs) { C = g.C + (int64_t)T.z * g.M * g.N; ldc = g.N; }
+  else { C = g.C + (int64_t)T.batch * g.sC; ldc = g.ldc; }
   const bool epi = !g.slabs;
   const bool by_n = epi && g.vec_axis == 0, by_m = epi && g.vec_axis == 1;
   const int rows_left = g.M - m0, cols_left = g.N - n0;                      // >= 1
   const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C + (int64_t)m0 * ldc + n0, ((int64_t)(rows_left - 1) * ldc + cols_left) * 4);
   const uint32_t voC = (uint32_t)(((wm + 4 * h) * (uint32_t)ldc + wn + l31) * 4);
   const bool has_res = epi && g.residual != nullptr;
-  const float* Rp = has_res ? g.residual + (int64_t)batch * g.sR + (int64_t)m0 * g.ldr + n0 : C;
+  const float* Rp = has_res ? g.residual + (int64_t)T.batch * g.sR + (int64_t)m0 * g.ldr + n0 : C;
   const __amdgpu_buffer_rsrc_t rsR = make_rsrc(Rp, has_res ? ((int64_t)(rows_left - 1) * g.ldr + cols_left) * 4 : 0);
   const uint32_t voR = (uint32_t)(((wm + 4 * h) * (uint32_t)g.ldr + wn + l31) * 4);
   const bool m_scale = by_m && g.scale != nullptr, m_shift = by_m && g.shift != nullptr;
@@ -405,6 +395,48 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   }
 }
 
+// Persistent workgroups: the grid is (at most) one residency of the chip, and a workgroup walks tiles t = blockIdx,
+// blockIdx + grid, ...  Between the k loop of a tile and its epilogue it decodes the NEXT tile and issues that tile's
+// first global loads, so the store burst of the epilogue (and the launch / address set-up a fresh workgroup would pay)
+// overlaps the latency of the next tile's first operands.
+template <int PREC, int ALAY, int BLAY>
+__global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
+  constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * IMGS * IMG_DWORDS];
+  uint32_t* imgA = lds;
+  uint32_t* imgB = lds + IMGS * IMG_DWORDS;
+  const int tid = threadIdx.x;
+  const uint32_t voa = ALAY == LAY_K ? voff_kmajor<PREC>(g.lda, tid) : voff_mnmajor<PREC>(g.lda, tid);
+  const uint32_t vob = BLAY == LAY_K ? voff_kmajor<PREC>(g.ldb, tid) : voff_mnmajor<PREC>(g.ldb, tid);
+  Staged<PREC> sa, sb;
+  int t = blockIdx.x;
+  if (t >= g.total) return;
+  Tile cur = decode_tile<PREC, ALAY, BLAY>(g, t);
+  if (cur.kbeg < cur.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, cur, cur.kbeg, tid, voa, vob);
+  for (;;) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    mainloop<PREC, ALAY, BLAY>(acc, sa, sb, g, cur, imgA, imgB, tid, voa, vob);
+    const int tn = t + (int)gridDim.x;
+    const bool more = tn < g.total;
+    const bool early = more && !(g.ablate & 16);
+    if (early) {       // only the tile NUMBER survives the epilogue (registers): the next tile is decoded twice
+      const Tile nxt = decode_tile<PREC, ALAY, BLAY>(g, tn);
+      if (nxt.kbeg < nxt.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, nxt, nxt.kbeg, tid, voa, vob);
+    }
+    epilogue(acc, g, cur, tid);
+    if (!more) break;
+    cur = decode_tile<PREC, ALAY, BLAY>(g, tn);
+    if (!early && cur.kbeg < cur.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, cur, cur.kbeg, tid, voa, vob);
+    t = tn;
+  }
+}
+
 // C[m, n] = epilogue( sum_z slab[z][m, n] ), slabs summed in z order (deterministic)
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __restrict__ ws, int Z, GemmArgs g) {
   const int64_t total = (int64_t)g.M * g.N;
@@ -425,6 +457,17 @@ void launch(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStream_
   else if (a_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_MN>), grid, dim3(THREADS), 0, st, g);
   else if (b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_K>), grid, dim3(THREADS), 0, st, g);
   else hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_MN>), grid, dim3(THREADS), 0, st, g);
+}
+
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
 }
 
 // how many k-splits a reduced product gets: enough workgroups for ~2 per CU, k chunks of at least 4 k-steps
@@ -486,13 +529,19 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   g.k_chunk = ((K + g.splits - 1) / g.splits + bk - 1) / bk * bk;
   const int Z = batch * g.splits;
   g.slabs = (reduce && Z > 1) ? 1 : 0;
-  if ((int64_t)g.tiles_m * g.tiles_n > 0x7fffffff / 2 || Z > 65535) return VIDAR_ERR_BAD_ARG;
+  if ((int64_t)g.tiles_m * g.tiles_n * Z > 0x3fffffff) return VIDAR_ERR_BAD_ARG;
   GemmArgs k = g;
   if (g.slabs) {
     if (workspace == nullptr || workspace_bytes < (size_t)Z * M * N * sizeof(float)) return VIDAR_ERR_BAD_ARG;
     k.C = (float*)workspace;
   }
-  dim3 grid(g.tiles_m * g.tiles_n, Z);
+  k.total = g.tiles_m * g.tiles_n * Z;
+  // one residency of the chip: 3 (bf16x3: 40 KB of LDS, 168 registers) / 4 (fp32) workgroups per CU, a multiple of 8
+  // so that t & 7 stays the workgroup's XCD for every tile it walks
+  const int resident = num_cus() * (precision == PREC_BF16X3 ? 3 : 4) / 8 * 8;
+  const char* pe = getenv("VIDAR_GEMM_PERSIST");
+  const bool persist = !(pe && pe[0] == '0');
+  dim3 grid(persist && k.total > resident ? resident : k.total);
   if (precision == PREC_BF16X3) launch<PREC_BF16X3>(k, a_layout, b_layout, grid, st);
   else launch<PREC_F32>(k, a_layout, b_layout, grid, st);
   if (g.slabs) {
