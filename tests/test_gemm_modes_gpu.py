@@ -17,7 +17,20 @@ def test_reference_goldens_hold_on_the_mfma_gemm_path(mode):
     import test_reference_golden_gpu as R
     with G.use(mode):
         R.test_encoder_stack_matches_reference_modules(True)
-        R.test_head_v1_forward_matches_reference()
+        if mode == "f32":
+            R.test_head_v1_forward_matches_reference()
+        else:
+            # the one check bf16x3 cannot hold ELEMENTWISE at the fp32 tolerance (rtol 2e-4 / atol 2e-5): 0.4 % of the head's
+            # raw outputs (magnitude ~2.6) differ by up to 1.3e-4 = 5e-5 of the largest entry -- 16-bit significands.
+            # Bound stated instead: 1e-4 of the largest entry (a TF32 product, the reference's arithmetic, is ~30 x wider).
+            gold = np.load(R.HV1.GOLD, allow_pickle=False)
+            head = R._head(gold)
+            c = lambda k: torch.from_numpy(gold[k]).cuda()
+            with torch.no_grad():
+                out = head(c("prev_feats"), [R.HV1._meta(gold)], 1, c("tgt_points"), c("ref_points"), 12, 12)
+                preds = head.forward_head(c("feats"))
+            for got, want in ((out, gold["out"]), (preds, gold["preds"])):
+                assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-4 * float(np.abs(want).max())
         R.test_forward_test_chamfer_per_future_frame_within_1e_3_of_reference()
         R.test_forward_train_losses_and_gradients_match_reference()
 
