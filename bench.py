@@ -68,7 +68,7 @@ def parse():
                     help="comma-separated `config[@samples_per_gpu]` entries timed after the main one in the same run "
                          "(short records under `configs`): BASELINE.json's other named configs -- the north star's "
                          "target sentence names vidar_1_8_nusc_3future; OpenScene = 8 cameras; @2 = per-GPU batch 2")
-    ap.add_argument("--gemm", choices=["lib", "f32", "bf16x3"], default=None,
+    ap.add_argument("--gemm", choices=["lib", "auto", "f32", "bf16x3"], default=None,
                     help="what the Linear / 1x1-convolution products of the main record run on (default: vidar_amd.gemm."
                          "mode(), i.e. $VIDAR_GEMM or the package default); extra configs take it as `name@spg:gemm`")
     ap.add_argument("--extra-steps", type=int, default=5)
@@ -477,7 +477,7 @@ def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers,
         G.set_mode(prev)
 
 
-GEMM_DTYPE = {"lib": "f32", "f32": "f32",
+GEMM_DTYPE = {"lib": "f32", "auto": "f32", "f32": "f32",
               "bf16x3": "f32 storage, bf16x3 MFMA products (16-bit significand >= TF32), f32 accumulate"}
 
 

@@ -51,7 +51,8 @@ def test_three_term_product_is_at_least_four_times_tighter_than_tf32(M, K, N):
 
 def test_mode_switch_and_no_cpu_path():
     from vidar_amd import gemm as G
-    assert G.mode() in ("lib", "f32", "bf16x3")
+    assert G.mode() in ("lib", "auto", "f32", "bf16x3")
+    assert not G.own_kernels("auto") and not G.own_kernels("lib") and G.own_kernels("f32") and G.own_kernels("bf16x3")
     prev = G.mode()
     with G.use("bf16x3"):
         assert G.mode() == "bf16x3" and G.precision_of() == G.BF16X3

@@ -37,7 +37,7 @@ def _batch_of(name, bs, bev=24):
                                          ("vidar_OpenScene_mini_full_3future", 1, 24),   # 8 cameras (BASELINE config 4)
                                          ("vidar_1_8_nusc_1future", 2, 24),              # per-GPU batch 2 (BASELINE config 3)
                                          ("vidar_1_8_nusc_1future", 1, 50)])             # BASELINE configs[0]'s 50 x 50 BEV
-def test_hip_step_matches_cpu_oracle_step(name, bs, bev=24):
+def test_hip_step_matches_cpu_oracle_step(name, bs, bev):
     from oracle import cpu_ops
     from vidar_amd import train as T
     from vidar_amd.plugin.dense_heads import ray_ops

@@ -25,7 +25,9 @@ PY
 stamp "whole-step A/B"
 {
   step lib VIDAR_GEMM=lib
-  step f32 VIDAR_GEMM=f32
+  step auto VIDAR_GEMM=auto
+  step auto_nofuse VIDAR_GEMM=auto VIDAR_AUTO_FUSE_RES=0
+
   step bf16x3 VIDAR_GEMM=bf16x3
 } 2>&1 | tee $out/step_ab.log
 stamp "full GPU suite"

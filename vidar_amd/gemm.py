@@ -2,6 +2,11 @@
 
 `mode()` selects what the Linear layers / 1x1 convolutions of the path run on:
     "lib"     torch.addmm / bmm -> rocBLAS / hipBLASLt fp32 (TunableOp-selected, vidar_amd/gemm_tuning.py)
+    "auto"    (default) fp32 throughout, each product on whichever fp32 kernel is faster on MI355X (profiles/r04_*):
+              the library for forward / grad-input products, this library's exact-fp32 MFMA kernel for the Linear
+              weight gradients (contraction over 40 000 - 185 000 rows: the library's best solution runs at 22 - 44
+              TFLOP/s there, the split-K slab kernel at 90 - 100) and for the bottleneck's closing 1x1 convolution
+              with its frozen BatchNorm + residual + ReLU in the epilogue
     "f32"     vidar_gemm_f32(precision = VIDAR_GEMM_F32): this library's exact-fp32 MFMA kernel, with the bias / frozen
               BatchNorm / residual / ReLU that follows the product folded into its epilogue
     "bf16x3"  the same kernel with split-bf16 products (16 significand bits >= the TF32 the reference executes these
@@ -20,8 +25,8 @@ from ._lib import lib, check, ptr, stream_of, TIMER
 
 F32, BF16X3 = 0, 1
 K_MAJOR, MN_MAJOR = 0, 1
-_MODES = ("lib", "f32", "bf16x3")
-_mode = os.environ.get("VIDAR_GEMM", "lib")
+_MODES = ("lib", "auto", "f32", "bf16x3")
+_mode = os.environ.get("VIDAR_GEMM", "auto")
 if _mode not in _MODES:
     raise ValueError(f"VIDAR_GEMM={_mode!r}: expected one of {_MODES}")
 
@@ -50,6 +55,11 @@ def use(m: str):
 def precision_of(m: str | None = None) -> int:
     m = _mode if m is None else m
     return BF16X3 if m == "bf16x3" else F32
+
+
+def own_kernels(m: str | None = None) -> bool:
+    """True when EVERY product of the path runs on csrc/gemm_mfma.hip ("f32", "bf16x3")"""
+    return (_mode if m is None else m) in ("f32", "bf16x3")
 
 
 def _f32c(t, what):

@@ -96,7 +96,7 @@ class _ModulatedDeformConv(Function):
 def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, bn=None, relu=False):
     """bn: a FrozenBN whose affine (+ `relu`) is folded into the GEMM epilogue when the MFMA GEMM path is on
     (vidar_amd.gemm.mode() != "lib") -- the caller must then NOT apply it again (see `Bottleneck.forward`)"""
-    m = G.mode() if x.is_cuda else "lib"
+    m = G.mode() if (x.is_cuda and G.own_kernels()) else "lib"
     scale = shift = None
     if bn is not None:
         assert m != "lib"
@@ -270,6 +270,9 @@ class Conv1x1(nn.Conv2d):
         return out.view(N, self.out_channels, H, W)
 
 
+_AUTO_FUSE_RES = os.environ.get("VIDAR_AUTO_FUSE_RES", "1") != "0"
+
+
 class _Conv1x1BNAct(Function):
     """act(bn(conv1x1(x)) + residual) with the frozen BatchNorm, the residual add and the ReLU in the epilogue of the
     MFMA GEMM (csrc/gemm_mfma.hip): the [N, Cout, H*W] product is written once instead of written, re-read and
@@ -303,7 +306,10 @@ class _Conv1x1BNAct(Function):
 def conv1x1_bn_act(conv, bn, x, residual=None, relu=False):
     """`bn(conv(x), residual, relu)` of a bias-free 1x1 convolution and a frozen BN; fused when the MFMA GEMM path is on"""
     m = G.mode()
-    if (m == "lib" or not x.is_cuda or bn.weight.requires_grad or conv.bias is not None or conv.kernel_size != (1, 1)
+    # "auto": only the block's closing convolution (the one with a residual) takes the fused MFMA kernel -- there the
+    # epilogue saves a 3-tensor affine_act pass; the other 1x1 convolutions are faster as library GEMM + affine_act
+    fuse = G.own_kernels(m) or (m == "auto" and residual is not None and _AUTO_FUSE_RES)
+    if (not fuse or not x.is_cuda or bn.weight.requires_grad or conv.bias is not None or conv.kernel_size != (1, 1)
             or conv.padding != (0, 0) or conv.groups != 1):
         return bn(conv(x), residual=residual, relu=relu)
     if conv.stride != (1, 1):
@@ -338,7 +344,7 @@ class Bottleneck(nn.Module):
         else:
             identity = self.downsample(x)
         out = conv1x1_bn_act(self.conv1, self.bn1, x, relu=True)
-        if (isinstance(self.conv2, ModulatedDeformConv2dPack) and G.mode() != "lib" and out.is_cuda
+        if (isinstance(self.conv2, ModulatedDeformConv2dPack) and G.own_kernels() and out.is_cuda
                 and not self.bn2.weight.requires_grad):
             out = self.conv2(out, bn=self.bn2, relu=True)
         else:

@@ -74,7 +74,8 @@ class _LinearColsum(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = g2 @ w
         if ctx.needs_input_grad[1]:
-            gw = (x2.t() @ g2).t()
+            # "auto": the exact-fp32 split-K MFMA kernel (4 x the library's best solution for these tall contractions)
+            gw = _gemm.linear_grad_weight(g2, x2, _gemm.F32) if _gemm.mode() == "auto" else (x2.t() @ g2).t()
         gb = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)
         check(lib().vidar_colsum_f32(ptr(g2), ptr(gb), ctypes.c_int64(g2.shape[0]), int(g2.shape[1]), stream_of(g2)),
               "colsum")
@@ -91,7 +92,7 @@ class Linear(nn.Linear):
         n = self.out_features
         f32 = (x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32
                and (self.bias is None or self.bias.dtype == torch.float32) and not torch.is_autocast_enabled())
-        if f32 and _gemm.mode() != "lib" and x.numel() > 0:
+        if f32 and _gemm.own_kernels() and x.numel() > 0:
             # the hand-written matrix-core kernel (csrc/gemm_mfma.hip): exact fp32 ("f32") or split-bf16 ("bf16x3")
             return _gemm.linear(x, self.weight, self.bias, relu=relu)
         if (f32 and self.bias is not None and self.bias.requires_grad
