@@ -140,8 +140,6 @@ def test_conv1x1_as_batched_gemm_equals_conv2d(stride, bias):
     assert sorted(m.state_dict()) == (["bias", "weight"] if bias else ["weight"]) and m.weight.shape == (40, 24, 1, 1)
 
 
-@pytest.mark.skipif(os.environ.get("VIDAR_STAGED") != "1",
-                    reason="staged kernel (written without a GPU): tools/first_gpu_call.sh runs it with VIDAR_STAGED=1")
 @pytest.mark.parametrize("shape", [(2, 3, 8, 8), (1, 4, 7, 12), (1, 2, 1, 4), (3, 64, 58, 100), (2, 64, 464, 800)])
 def test_fused_stem_pool_matches_two_kernel_path(shape):
     """vidar_stem_bn_relu_pool_f32 == max_pool2d(FrozenBN(x, relu=True), 3, 2, 1), bit for bit"""

@@ -17,9 +17,9 @@ ROOT = Path(__file__).resolve().parents[1]
 L = 1026
 
 
-# the header's compile-time variants: the shipped one, and the staged one that consumes a sample's density one
-# commit later (VIDAR_DVR_PIPELINED_SIGMA, same arithmetic in the same order -- see dvr_march.h)
-BUILDS = {"default": [], "pipelined_sigma": ["-DVIDAR_DVR_PIPELINED_SIGMA"]}
+# the header as shipped: a sample's density is consumed one commit later (same arithmetic in the same order, see
+# dvr_march.h; on the GPU the load gets a whole traversal step to arrive: dvxlr.render 0.254 -> 0.225 ms at 30 000 rays)
+BUILDS = {"default": []}
 
 
 def _build(tmp_path_factory, flags):
@@ -123,33 +123,3 @@ def test_dvr_render(host, name, make, loss):
     np.testing.assert_array_equal(gt, ref[1])
     scale = max(1.0, float(np.abs(ref[2]).max()))
     np.testing.assert_allclose(grad, ref[2], rtol=1e-4, atol=1e-4 * scale)
-
-
-def test_pipelined_sigma_build_is_bitwise_the_default_build(tmp_path_factory):
-    """every output byte of dvxlr.render_v2, dvr.render_forward and dvr.render, on a volume with long rays"""
-    a, b = (_build(tmp_path_factory, f) for f in BUILDS.values())
-    rng = np.random.default_rng(5)
-    Z, Y, X, M = 8, 60, 60, 3000
-    sigma = rng.uniform(0, 0.2, (1, 2, Z, Y, X)).astype(np.float32)
-    sigma[rng.uniform(size=sigma.shape) < 0.3] = 0.0
-    reg = rng.random(sigma.shape, dtype=np.float32)
-    origin = rng.uniform([20, 20, 2], [40, 40, 6], (1, 2, 3)).astype(np.float32)
-    pts = rng.uniform([-10, -10, -2], [X + 10, Y + 10, Z + 2], (1, M, 3)).astype(np.float32)
-    tindex = rng.integers(-1, 2, (1, M)).astype(np.float32)
-    sigma, origin, pts, tindex, dims = _prep(sigma, origin, pts, tindex)
-    outs = []
-    for h in (a, b):
-        pred = np.empty((1, M), np.float32); gt = np.empty((1, M), np.float32)
-        dd = np.empty((1, M, L), np.float32); idx = np.empty((1, M, L, 3), np.float32)
-        rp = np.empty((1, M, L), np.float32); ind = np.empty((1, M, L), np.float32)
-        est = np.zeros((1, M), np.int32)
-        assert h.host_dvxlr_render(_p(sigma), _p(reg), _p(origin), _p(pts), _p(tindex), _p(pred), _p(gt), _p(dd),
-                                   _p(idx), _p(rp), _p(ind), _p(est), *dims) == 0
-        p2 = np.empty((1, M), np.float32); g2 = np.empty((1, M), np.float32)
-        assert h.host_dvr_render_forward(_p(sigma), _p(origin), _p(pts), _p(tindex), _p(p2), _p(g2), *dims, 1) == 0
-        p3 = np.empty((1, M), np.float32); g3 = np.empty((1, M), np.float32); grad = np.empty(sigma.shape, np.float64)
-        assert h.host_dvr_render(_p(sigma), _p(origin), _p(pts), _p(tindex), _p(p3), _p(g3), _p(grad), *dims, 1) == 0
-        outs.append([pred, gt, dd, idx, rp, ind, p2, g2, p3, g3, grad])
-    assert (outs[0][3] != 0).any(-1).sum(-1).max() > 60          # long rays are in the sample
-    for x, y in zip(*outs):
-        assert x.tobytes() == y.tobytes()

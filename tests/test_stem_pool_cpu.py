@@ -47,28 +47,3 @@ def test_thread_program_equals_bn_relu_maxpool(shape):
     out = thread_program(x, s, b)
     assert out.shape == ref.shape and not np.isnan(out).any()     # every output written
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-6)       # numpy's a*s+b is not fused: last-bit slack only
-
-
-@pytest.mark.parametrize("hw", [(8, 12), (20, 14), (58, 100)])
-def test_space_to_depth_form_of_the_stem_convolution(hw):
-    """backbones.stem_conv_space_to_depth == the 7x7 / stride 2 / padding 3 convolution (same products, another
-    summation order: fp32 round-off only); refuses what it cannot express"""
-    import torch.nn as nn
-    from vidar_amd.plugin.backbones import stem_conv_space_to_depth
-    torch.manual_seed(0)
-    conv = nn.Conv2d(3, 16, 7, stride=2, padding=3, bias=False).double()
-    conv.weight.requires_grad = False
-    x = torch.randn(2, 3, *hw, dtype=torch.float64)
-    ref = conv(x)
-    out = stem_conv_space_to_depth(conv, x)
-    assert out.shape == ref.shape
-    torch.testing.assert_close(out, ref, rtol=1e-12, atol=1e-12)
-    conv32 = nn.Conv2d(3, 16, 7, stride=2, padding=3, bias=False)
-    conv32.weight.requires_grad = False
-    x32 = torch.randn(1, 3, *hw)
-    torch.testing.assert_close(stem_conv_space_to_depth(conv32, x32), conv32(x32), rtol=1e-4, atol=1e-5)
-    assert stem_conv_space_to_depth(conv32, torch.randn(1, 3, hw[0] + 1, hw[1])) is None       # odd height
-    assert stem_conv_space_to_depth(nn.Conv2d(3, 16, 7, stride=2, padding=3, bias=False), x32) is None   # trainable
-    with torch.no_grad():                                      # the rearranged weight follows an update of the original
-        conv32.weight.mul_(2.0)
-    torch.testing.assert_close(stem_conv_space_to_depth(conv32, x32), conv32(x32), rtol=1e-4, atol=1e-5)

@@ -180,21 +180,19 @@ def bench_affine(which):
 
 
 def bench_stem(which):
-    """The ResNet stem at the 24 history images: conv1 as MIOpen's 7x7 / stride 2 vs the 4x4 space-to-depth form, and
-    BN + ReLU + max-pool as affine_act + torch's pooling vs the one-pass kernel (both staged)."""
+    """The ResNet stem at the 24 history images: conv1 (MIOpen's 7x7 / stride 2), and BN + ReLU + max-pool as affine_act +
+    torch's pooling vs the one-pass kernel the backbone uses."""
     import torch.nn as nn
     import torch.nn.functional as F
-    from vidar_amd.plugin.backbones import FrozenBN, stem_bn_relu_pool, stem_conv_space_to_depth
+    from vidar_amd.plugin.backbones import FrozenBN, stem_bn_relu_pool
     conv = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False).cuda()
     conv.weight.requires_grad = False
     bn = FrozenBN(64).cuda()
     x = torch.randn(24, 3, 928, 1600, device="cuda")
     flops = 2 * 24 * 64 * 464 * 800 * 147
     with torch.no_grad():
-        for name, fn in (("conv1 7x7 stride 2 (MIOpen)", lambda: conv(x)),
-                         ("conv1 as 4x4 over space-to-depth", lambda: stem_conv_space_to_depth(conv, x))):
-            ms = timeit(fn)
-            print(json.dumps({"op": f"stem {name}", "ms": round(ms, 4), "TFLOPs_of_the_7x7": round(flops / ms / 1e9, 1)}))
+        ms = timeit(lambda: conv(x))
+        print(json.dumps({"op": "stem conv1 7x7 stride 2 (MIOpen)", "ms": round(ms, 4), "TFLOPs": round(flops / ms / 1e9, 1)}))
         y = conv(x)
         nb = 4 * (y.numel() + y.numel() // 4)
         report("stem bn+relu+pool two kernels", timeit(lambda: F.max_pool2d(bn(y, relu=True), 3, stride=2, padding=1)), nb)

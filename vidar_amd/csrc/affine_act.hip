@@ -13,9 +13,6 @@
 #include "vidar_hip.h"
 #include "vidar_common.h"
 
-#ifndef VIDAR_AA_ILP
-#define VIDAR_AA_ILP 1           // float4 elements per thread of the forward kernel whose loads are issued together
-#endif
 
 namespace {
 
@@ -32,33 +29,6 @@ __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __rest
   const size_t base = (size_t)plane * HW;
   if (VEC) {
     const int n4 = HW >> 2;
-#if VIDAR_AA_ILP > 1
-    // staged (tools/staged_variants.sh): kIlp float4 per thread, all loads issued before the first use -- twice / four
-    // times the bytes in flight per wave (aa_grid launches correspondingly fewer workgroups per plane)
-    constexpr int kIlp = VIDAR_AA_ILP;
-    for (int i0 = blockIdx.x * 256 * kIlp + threadIdx.x; i0 < n4; i0 += gridDim.x * 256 * kIlp) {
-      float4 v[kIlp], r[kIlp];
-#pragma unroll
-      for (int u = 0; u < kIlp; ++u) {
-        const int i = i0 + u * 256;
-        if (i < n4) {
-          v[u] = reinterpret_cast<const float4*>(x + base)[i];
-          if (res) r[u] = reinterpret_cast<const float4*>(res + base)[i];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kIlp; ++u) {
-        const int i = i0 + u * 256;
-        if (i < n4) {
-          float4 o = v[u];
-          o.x = o.x * s + b; o.y = o.y * s + b; o.z = o.z * s + b; o.w = o.w * s + b;
-          if (res) { o.x += r[u].x; o.y += r[u].y; o.z += r[u].z; o.w += r[u].w; }
-          if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-          reinterpret_cast<float4*>(y + base)[i] = o;
-        }
-      }
-    }
-#else
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
       float4 v = reinterpret_cast<const float4*>(x + base)[i];
       v.x = v.x * s + b; v.y = v.y * s + b; v.z = v.z * s + b; v.w = v.w * s + b;
@@ -69,7 +39,6 @@ __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float* __rest
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       reinterpret_cast<float4*>(y + base)[i] = v;
     }
-#endif
   } else {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
       float v = x[base + i] * s + b;
@@ -113,7 +82,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
 
 // VEC forward: float4 elements a workgroup covers per pass (the backward kernel keeps one per thread)
 inline dim3 aa_grid_fwd(int N, int C, int HW) {
-  int bx = (HW / 4 + 256 * VIDAR_AA_ILP - 1) / (256 * VIDAR_AA_ILP);
+  int bx = (HW / 4 + 255) / 256;
   if (bx < 1) bx = 1;
   if (bx > 64) bx = 64;
   return dim3(bx, N * C);

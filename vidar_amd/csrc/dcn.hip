@@ -106,19 +106,7 @@ __global__ __launch_bounds__(256) void dcn_im2col_kernel(const float* __restrict
 // weights times the mask, with the zero padding folded into the weights -- is computed once per (pixel, tap) and
 // reused for the kCP channels of the thread's group.  The pair starts at column c0 = clamp(w0, 0, W-2): for
 // w0 == -1 the right corner is element 0 of the pair, for w0 == W-1 the left corner is element 1.
-#ifndef VIDAR_DCN_CP
-#define VIDAR_DCN_CP 16          // channels per thread; 8 needs 52 instead of 85 VGPRs and no scalar spills (tools/staged_variants.sh)
-#endif
-constexpr int kCP = VIDAR_DCN_CP;
-#ifndef VIDAR_DCN_NT_STORES
-#define VIDAR_DCN_NT_STORES 0    // im2col: column stores with the non-temporal policy
-#endif
-#ifndef VIDAR_DCN_SEGMENTED_SCAN
-#define VIDAR_DCN_SEGMENTED_SCAN 0  // col2im reverse map: one scan workgroup per (image, tap) list instead of per image
-#endif
-#ifndef VIDAR_DCN_COORD_BATCH
-#define VIDAR_DCN_COORD_BATCH 1  // channels whose loads dcn_col2im_coord_kernel issues together (1 = one channel at a time)
-#endif
+constexpr int kCP = 16;
 typedef float pair_t __attribute__((ext_vector_type(2), aligned(4)));
 
 struct PairFoot {
@@ -207,14 +195,11 @@ __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __res
     for (int c = 0; c < kCP; ++c)
       if (c < nc) {
         const float v = f.wt0 * a[c].x + f.wt1 * a[c].y + f.wb0 * b[c].x + f.wb1 * b[c].y;
-#if VIDAR_DCN_NT_STORES
-        // staged: the column matrix is written once and read by the GEMM much later (1.28 GB per call at stage 3); the
-        // counters show the 71 MB input fetched 4 x from HBM (profiles/r03_pmc_dcn) -- the write stream evicts the
-        // planes the next taps re-read.  Streaming stores leave them in L2.
+        // the column matrix is written once and read by the GEMM much later (1.28 GB per call at stage 3); the counters
+        // showed the 71 MB input fetched 4 x from HBM (profiles/r03_pmc_dcn) -- the write stream evicted the planes the
+        // next taps re-read.  Streaming (non-temporal) stores leave them in L2: 0.399 -> 0.330 ms per call at stage 3
+        // (profiles/r04_staged_variants_kernel_times.log).
         __builtin_nontemporal_store(v, out + (size_t)c * KP + (size_t)t * P);
-#else
-        out[(size_t)c * KP + (size_t)t * P] = v;
-#endif
       }
   }
 }
@@ -393,11 +378,10 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(
     const float w_t0 = e0(-hh * tl, hh * tr), w_t1 = e1(-hh * tl, hh * tr);
     const float w_b0 = e0(-q.lh * bl, q.lh * br), w_b1 = e1(-q.lh * bl, q.lh * br);
     int c = 0;
-#if VIDAR_DCN_COORD_BATCH > 1
-    // staged (tools/staged_variants.sh): the loop below keeps 3 loads in flight per thread and waits for them 256
-    // times in a row (the compiler does not cluster the loads of an unrolled body by itself); here the loads of
-    // kCB channels are issued together, the sums are still taken in channel order
-    constexpr int kCB = VIDAR_DCN_COORD_BATCH;
+    // one channel per iteration keeps 3 loads in flight per thread and waits for them 256 times in a row (the compiler
+    // does not cluster the loads of an unrolled body by itself): the loads of kCB channels are issued together, the
+    // sums are still taken in channel order (0.654 -> 0.577 ms at stage 4, profiles/r04_staged_variants_kernel_times.log)
+    constexpr int kCB = 8;
     const unsigned top_b = (unsigned)top * 4u, bot_b = (unsigned)bot * 4u, p_b = (unsigned)p * 4u;   // plane < 2^30 B
     const size_t plane_b = (size_t)g.H * g.W * 4, col_b = (size_t)K * P * 4;
     for (; c + kCB <= g.C; c += kCB) {
@@ -420,7 +404,6 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(
         gw += gc[u] * (w_t0 * a[u].x + w_t1 * a[u].y + w_b0 * b[u].x + w_b1 * b[u].y);
       }
     }
-#endif
     for (; c < g.C; ++c) {
       const float* im = x + ((size_t)n * g.C + c) * g.H * g.W;
       const float gc = grad_cols[(((size_t)n * g.C + c) * K + t) * P + p];
@@ -503,13 +486,9 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
     if (e != hipSuccess) return (int)e;
     const dim3 rgrid((P + 255) / 256, K, N);
     hipLaunchKernelGGL(dcn_revmap_kernel<false>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
-#if VIDAR_DCN_SEGMENTED_SCAN
-    // staged (tools/staged_variants.sh): a (image, tap) list never holds more than 4 P entries, so every list can own
-    // a fixed slice of `rec` and be scanned by its own workgroup -- N K workgroups instead of N (0.1 ms per call on 6 CUs)
+    // a (image, tap) list never holds more than 4 P entries, so every list owns a fixed slice of `rec` and is scanned
+    // by its own workgroup -- N K workgroups instead of N (a scan per image kept 6 CUs busy for 0.1 ms per call)
     hipLaunchKernelGGL(dcn_revmap_scan_kernel, dim3(N * K), dim3(1024), 0, s, cursor, first, HW, P * 4);
-#else
-    hipLaunchKernelGGL(dcn_revmap_scan_kernel, dim3(N), dim3(1024), 0, s, cursor, first, K * HW, K * P * 4);
-#endif
     hipLaunchKernelGGL(dcn_revmap_kernel<true>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
     hipLaunchKernelGGL(dcn_col2im_gather_kernel, dim3((HW + 255) / 256, (C + kGC - 1) / kGC, N), dim3(256), 0, s,
                        grad_cols, first, cursor, rec, grad_x, g);

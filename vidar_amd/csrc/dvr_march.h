@@ -152,25 +152,6 @@ struct Integrator {
 
   VIDAR_DEV Integrator(const float* s, int Y_, int X_, Emit& e) : sig(s), Y(Y_), X(X_), emit(e) {}
 
-#ifndef VIDAR_DVR_PIPELINED_SIGMA
-  VIDAR_DEV void commit(int vid, double d, double dt) {
-    const double sg = (double)sig[vid];
-    double w_prev = 0.0;                       // W_{k-1} = T_{k-1} (d_k - d_{k-1})
-    if (k == 0) {
-      d0 = d;
-    } else {
-      w_prev = Tprev * (d - dprev);
-      S += w_prev;
-    }
-    emit.commit(k, vid, d, dt, S, w_prev);
-    csd = (k == 0) ? sg * dt : csd + sg * dt;
-    // the transmittance only scales value outputs (1e-7 relative is plenty for fp32 results);
-    // csd itself and every traversal quantity stay fp64
-    Tprev = (double)expf((float)(-csd));
-    dprev = d;
-    ++k;
-  }
-#else
   // Same arithmetic, same order per sample -- but the density of sample k is only CONSUMED by commit k+1 (the
   // transmittance T_k first matters for W_k = T_k (d_{k+1} - d_k)), so its load has a whole traversal step to
   // arrive instead of stalling the lane right after it is issued; the last sample's density is never needed.
@@ -195,7 +176,6 @@ struct Integrator {
     dprev = d;
     ++k;
   }
-#endif
 
   VIDAR_DEV bool sample(int x, int y, int z, double d, double last_d) {
     const int vid = (z * Y + y) * X + x;

@@ -38,7 +38,6 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "vidar_hip.h"
 #include "vidar_common.h"
@@ -73,7 +72,6 @@ struct GemmArgs {
   int relu;
   int tiles_m, tiles_n, m_fastest;
   int total;       // tiles_m * tiles_n * (batch * splits)
-  int ablate;      // diagnosis only (VIDAR_GEMM_ABLATE): bit 0 no global loads after a tile's first, 1 no MFMA, 2 no stores, 3 no LDS staging, 4 no cross-tile prefetch
 };
 
 // ---- staging: 16 (fp32 mode: 8) floats per operand per thread ----------------------------------------------------
@@ -292,14 +290,10 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, 
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
   for (int k0 = T.kbeg; k0 < T.kend; k0 += BK) {
-    if (!(g.ablate & 8)) {
-      if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
-      if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
-    }
+    if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
+    if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
     __syncthreads();
-    if (k0 + BK < T.kend && !(g.ablate & 1))
-      fetch<PREC, ALAY, BLAY>(sa, sb, g, T, k0 + BK, tid, voa, vob);          // in flight under the MFMAs below
-    if (!(g.ablate & 2))
+    if (k0 + BK < T.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, T, k0 + BK, tid, voa, vob);   // in flight under the MFMAs below
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       u32x4 fa[2][IMGS], fb[2][IMGS];
@@ -386,8 +380,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmAr
             y = y * sc[r] + sh[r] + rs[r];
             if (g.relu && !(y > 0.0f)) y = 0.0f;
           }
-          if (!(g.ablate & 4))
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC, voC,
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC, voC,
                                                   (uint32_t)((row * (uint32_t)ldc + 32 * j) * 4), 0);
         }
       }
@@ -424,15 +417,13 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
     mainloop<PREC, ALAY, BLAY>(acc, sa, sb, g, cur, imgA, imgB, tid, voa, vob);
     const int tn = t + (int)gridDim.x;
     const bool more = tn < g.total;
-    const bool early = more && !(g.ablate & 16);
-    if (early) {       // only the tile NUMBER survives the epilogue (registers): the next tile is decoded twice
+    if (more) {        // only the tile NUMBER survives the epilogue (registers): the next tile is decoded twice
       const Tile nxt = decode_tile<PREC, ALAY, BLAY>(g, tn);
       if (nxt.kbeg < nxt.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, nxt, nxt.kbeg, tid, voa, vob);
     }
     epilogue(acc, g, cur, tid);
     if (!more) break;
     cur = decode_tile<PREC, ALAY, BLAY>(g, tn);
-    if (!early && cur.kbeg < cur.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, cur, cur.kbeg, tid, voa, vob);
     t = tn;
   }
 }
@@ -522,7 +513,6 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   g.M = M; g.N = N; g.K = K;
   g.scale = scale; g.shift = shift; g.vec_axis = vec_axis; g.residual = residual; g.ldr = ldr; g.sR = strideR;
   g.relu = relu;
-  { const char* e = getenv("VIDAR_GEMM_ABLATE"); g.ablate = e ? atoi(e) : 0; }
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.m_fastest = M < N;
   g.splits = reduce ? pick_splits(M, N, K, batch, bk) : 1;
@@ -536,12 +526,11 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
     k.C = (float*)workspace;
   }
   k.total = g.tiles_m * g.tiles_n * Z;
-  // one residency of the chip: 3 (bf16x3: 40 KB of LDS, 168 registers) / 4 (fp32) workgroups per CU, a multiple of 8
-  // so that t & 7 stays the workgroup's XCD for every tile it walks
-  const int resident = num_cus() * (precision == PREC_BF16X3 ? 3 : 4) / 8 * 8;
-  const char* pe = getenv("VIDAR_GEMM_PERSIST");
-  const bool persist = !(pe && pe[0] == '0');
-  dim3 grid(persist && k.total > resident ? resident : k.total);
+  // one residency of the chip: 3 workgroups per CU (launch bounds: 3 waves per SIMD), a multiple of 8 so that t & 7
+  // stays the workgroup's XCD for every tile it walks.  (Measured against one workgroup per tile and against fetching
+  // the next tile after the epilogue: within noise of each other on MI355X, profiles/r04_kbench_gemm_*.)
+  const int resident = num_cus() * 3 / 8 * 8;
+  dim3 grid(k.total > resident ? resident : k.total);
   if (precision == PREC_BF16X3) launch<PREC_BF16X3>(k, a_layout, b_layout, grid, st);
   else launch<PREC_F32>(k, a_layout, b_layout, grid, st);
   if (g.slabs) {

@@ -31,15 +31,13 @@ constexpr int kZ = 16;
 constexpr int kThreads = 256;
 constexpr int kCellsPerBlock = kThreads / 64;
 
-// Staged (tools/staged_variants.sh), default 1 = off.  Every ray starts at the BEV centre, so the first waypoints of
-// all H*W rays scatter onto the same few cells: with VIDAR_LR_COPIES = n the backward kernels add into n private
-// copies of the gradient maps (workgroup i -> copy i mod n; neighbouring workgroups = neighbouring cells = nearly the
-// same ray) and a small kernel sums the copies -- n times fewer atomics per hot address for the same total number.
-// It separates "serialised on the hot addresses" from "bound by the total atomic rate" (DESIGN.md section 4).
-#ifndef VIDAR_LR_COPIES
-#define VIDAR_LR_COPIES 1
-#endif
-constexpr int kCopies = VIDAR_LR_COPIES;
+// Every ray starts at the BEV centre, so the first waypoints of all H*W rays scatter onto the same few cells and the
+// atomics on those addresses serialise: the backward kernels add into kCopies private copies of the gradient maps
+// (workgroup i -> copy i mod n; neighbouring workgroups = neighbouring cells = nearly the same ray) and a small kernel
+// sums the copies -- n times fewer atomics per hot address for the same total number.  Measured on MI355X
+// (profiles/r04_staged_variants_kernel_times.log): lr_prob_bwd 0.66 -> 0.48 ms, lr_gather_bwd 1.32 -> 1.08 ms with 8
+// copies, memset and sum included: the kernels were serialised on the hot addresses, not bound by the atomic rate.
+constexpr int kCopies = 8;
 // which private copy this workgroup adds into, as an offset in maps of [bs, Q, 16] (0 when the variant is off)
 __device__ __forceinline__ size_t copy_of_block() { return (size_t)(blockIdx.x % kCopies) * gridDim.y; }
 
@@ -205,11 +203,7 @@ __global__ __launch_bounds__(kThreads) void lr_prob_bwd_kernel(const float* __re
   if (q >= Q) return;
   const int lane = threadIdx.x & 63, z = lane & 15, ks = lane >> 4;
   const float* map = occ + (size_t)b * Q * kZ;
-#if VIDAR_LR_COPIES > 1
   float* gmap = grad_occ + (copy_of_block() + b) * Q * kZ;
-#else
-  float* gmap = grad_occ + (size_t)b * Q * kZ;
-#endif
   const Cell c = make_cell(q, g);
   // pass 1: the transmittance product
   float pr = 1.f;
@@ -286,13 +280,8 @@ __global__ __launch_bounds__(kThreads) void lr_gather_bwd_kernel(
   const int lane = threadIdx.x & 63, z = lane & 15, ks = lane >> 4;
   const float* pm = prob + (size_t)b * Q * kZ;
   const float* am = a + (size_t)b * Q * kZ;
-#if VIDAR_LR_COPIES > 1
   float* gpm = grad_prob + (copy_of_block() + b) * Q * kZ;
   float* gam = grad_a + (copy_of_block() + b) * Q * kZ;
-#else
-  float* gpm = grad_prob + (size_t)b * Q * kZ;
-  float* gam = grad_a + (size_t)b * Q * kZ;
-#endif
   const Cell c = make_cell(q, g);
   const size_t o = ((size_t)b * Q + q) * kZ + z;
   const float f = feat[o];
@@ -310,7 +299,6 @@ __global__ __launch_bounds__(kThreads) void lr_gather_bwd_kernel(
   }
 }
 
-#if VIDAR_LR_COPIES > 1
 __global__ __launch_bounds__(256) void lr_sum_copies_kernel(const float4* __restrict__ copies, float4* __restrict__ out,
                                                             size_t n4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -334,7 +322,6 @@ inline float* lr_scratch(size_t floats) {
   }
   return g_lr_scratch;
 }
-#endif
 
 inline bool lr_bad(int bs, int H, int W, int Z, int G, int act) {
   return bs < 0 || H <= 0 || W <= 0 || Z != kZ || G <= 0 || (act != 0 && act != 1);
@@ -364,7 +351,6 @@ int vidar_latent_render_prob_bwd_f32(const float* occ, const float* grad_path_pr
   if (bs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   Geo g{H, W, grid_num, step, act, 0.f};
-#if VIDAR_LR_COPIES > 1
   const size_t n = (size_t)bs * H * W * Z;
   float* sc = lr_scratch(2 * n * kCopies);
   if (!sc) return (int)hipErrorOutOfMemory;
@@ -373,12 +359,6 @@ int vidar_latent_render_prob_bwd_f32(const float* occ, const float* grad_path_pr
   hipLaunchKernelGGL(lr_prob_bwd_kernel, lr_grid(bs, H * W), dim3(kThreads), 0, s, occ, grad_path_prob, sc, H * W, g);
   hipLaunchKernelGGL(lr_sum_copies_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
                      (const float4*)sc, (float4*)grad_occ, n / 4);
-#else
-  hipError_t e = hipMemsetAsync(grad_occ, 0, sizeof(float) * (size_t)bs * H * W * Z, s);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(lr_prob_bwd_kernel, lr_grid(bs, H * W), dim3(kThreads), 0, s, occ,
-                     grad_path_prob, grad_occ, H * W, g);
-#endif
   return vidar_last_error();
 }
 
@@ -404,7 +384,6 @@ int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora
   if (bs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   Geo g{H, W, grid_num, step, 0, eps};
-#if VIDAR_LR_COPIES > 1
   const size_t n = (size_t)bs * H * W * Z;
   float* sc = lr_scratch(2 * n * kCopies);
   if (!sc) return (int)hipErrorOutOfMemory;
@@ -417,15 +396,6 @@ int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora
   const dim3 rg((unsigned)((n / 4 + 255) / 256));
   hipLaunchKernelGGL(lr_sum_copies_kernel, rg, dim3(256), 0, s, (const float4*)sp, (float4*)grad_path_prob, n / 4);
   hipLaunchKernelGGL(lr_sum_copies_kernel, rg, dim3(256), 0, s, (const float4*)sa, (float4*)grad_lora_a, n / 4);
-#else
-  const size_t bytes = sizeof(float) * (size_t)bs * H * W * Z;
-  hipError_t e = hipMemsetAsync(grad_path_prob, 0, bytes, s);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(grad_lora_a, 0, bytes, s);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(lr_gather_bwd_kernel, lr_grid(bs, H * W), dim3(kThreads), 0, s, path_prob,
-                     lora_a, feat, msum, grad_feat, grad_path_prob, grad_lora_a, H * W, g);
-#endif
   return vidar_last_error();
 }
 

@@ -121,9 +121,6 @@ __device__ __forceinline__ int64_t raw_index(int64_t item, int lp, int H, int Nq
 //   o = BYTE offset of the corner's 128-byte line of this item's head from `value` (32-bit: the host
 //   checks B*Nv*H*32*4 < 2^32); an invalid corner points at a valid line and carries weight / mask 0.
 // ---------------------------------------------------------------------------------------------
-#ifndef VIDAR_MSDA_SKIP_DEAD
-#define VIDAR_MSDA_SKIP_DEAD 0              // staged (tools/staged_variants.sh): items without a live sample skip their loads
-#endif
 constexpr int kRecF = 8;                    // floats per sample record
 constexpr int kGLv = 16;                    // levels supported by the gather kernels' level table
 
@@ -248,20 +245,8 @@ __device__ __forceinline__ void corner_records(const GLevels& lv, float* rec, in
   __syncthreads();
 }
 
-#ifndef VIDAR_MSDA_NT_LOADS
-#define VIDAR_MSDA_NT_LOADS 0               // staged: corner lines fetched with the non-temporal (streaming) cache policy
-#endif
 __device__ __forceinline__ float4 ldv(const float* __restrict__ value, unsigned byte_off) {
-#if VIDAR_MSDA_NT_LOADS
-  // the gathers miss the vector L1 on almost every line (L2 hit rate ~50 % on random points, every line used once per
-  // wave): the measured 0.43 ms is what "fill the line, then deliver it" costs at 64 B/clk, twice the delivery alone.
-  // A streaming load does not have to keep the line.
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(value) + byte_off));
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(value) + byte_off);
-#endif
 }
 
 __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
@@ -284,22 +269,6 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
   const unsigned sub16 = sub * 16;
   const float* r = smem + rec_at(it, 0, LP);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#if VIDAR_MSDA_SKIP_DEAD
-  {
-    // staged: an item none of whose samples carries weight (all outside the image / NaN: the padded slots of the
-    // cross attention when VIDAR_SCA_PAD_NAN=1) issues no corner loads; its 8 lanes each look at LP/8 records
-    bool mine = false;
-    for (int lp = sub; lp < LP; lp += kLanes) {
-      const float4 w = reinterpret_cast<const float4*>(smem + rec_at(it, lp, LP))[0];
-      mine |= (w.x != 0.f) | (w.y != 0.f) | (w.z != 0.f) | (w.w != 0.f);
-    }
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
-    if (((bal >> (threadIdx.x & 63 & ~(kLanes - 1))) & ((1u << kLanes) - 1)) == 0) {
-      *reinterpret_cast<float4*>(out + (item0 + it) * kCh + sub * 4) = acc;
-      return;
-    }
-  }
-#endif
 #pragma unroll 4
   for (int lp = 0; lp < LP; ++lp, r += kRecF) {
     const float4 w = reinterpret_cast<const float4*>(r)[0];
@@ -799,12 +768,6 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
     // (the DPP reductions are convergent operations, which keeps the compiler from unrolling a loop with a
     //  run-time trip count: unrolled by hand, 16 lines in flight per wave)
     int lp = 0;
-#if VIDAR_MSDA_SKIP_DEAD
-    bool mine = false;                      // staged: see msda_fwd_kernel; meta < 0 = sample outside
-    for (int k = sub; k < LP; k += kLanes) mine |= __float_as_int(smem[rec_at(it, k, LP) + 3]) >= 0;
-    const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
-    if (((bal >> (threadIdx.x & 63 & ~(kLanes - 1))) & ((1u << kLanes) - 1)) == 0) lp = LP;
-#endif
     for (; lp + 4 <= LP; lp += 4, r += 4 * kRecF) locw_samples<4>(value, r, go, sub, sub16);
     for (; lp < LP; ++lp, r += kRecF) locw_samples<1>(value, r, go, sub, sub16);
   }

@@ -131,56 +131,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 constexpr float kNegInf = -__builtin_inff();
 
-// Staged (tools/staged_variants.sh), default off.  The waypoints of a ray that lie inside the open volume are ONE run
-// of consecutive k (a line meets a convex box in a segment), and with the recipe's geometry that run is 60-140 of the
-// 512 waypoints: most passes of the kernels below only compute footprints that are then masked.  With
-// VIDAR_RAY_EARLY_EXIT a wave stops after the first pass without a live waypoint that follows a pass with one (passes
-// are blocks of consecutive k, so no later waypoint can be live); a masked waypoint contributes -inf / nothing, so
-// every result is unchanged.  tests/test_ray_early_exit_cpu.py checks the single-run property in the kernels' fp32
-// arithmetic.
-#ifndef VIDAR_RAY_EARLY_EXIT
-#define VIDAR_RAY_EARLY_EXIT 0
-#endif
-// Staged, default 1 = off: like VIDAR_LR_COPIES of latent_render.hip.  Every ray of a frame starts at the sensor origin,
-// so the first waypoints of all rays of a frame scatter onto the same 8-27 voxels (210 000 rays x ~3 waypoints x 8
-// corners onto ~190 addresses in one ray_ce_bwd launch: if an address retires one atomic per ~25 ns that alone is the
-// launch's 0.66 ms).  With VIDAR_RAY_COPIES = n the backward kernels add into n private copies of the gradient volume
-// (workgroup i -> copy i mod n) and a small kernel sums them.
-#ifndef VIDAR_RAY_COPIES
-#define VIDAR_RAY_COPIES 1
-#endif
-#if VIDAR_RAY_COPIES > 1
-constexpr int kRayCopies = VIDAR_RAY_COPIES;
-#endif
+// Every ray of a frame starts at the sensor origin, so the first waypoints of all rays of a frame scatter onto the same
+// 8-27 voxels (210 000 rays x ~3 waypoints x 8 corners onto ~190 addresses in one ray_ce_bwd launch) and the atomics on
+// those addresses serialise: the backward kernels add into kRayCopies private copies of the gradient volume
+// (workgroup i -> copy i mod n) and a small kernel sums them.  Measured on MI355X
+// (profiles/r04_staged_variants_kernel_times.log): ray_ce_bwd 0.69 -> 0.41 ms, ray_gumbel_bwd 0.41 -> 0.29 ms with 8
+// copies, memset and sum included.  (Leaving the 512-waypoint loops after the run of live waypoints -- the waypoints
+// inside the volume are ONE run of consecutive k, tests/test_ray_early_exit_cpu.py -- was measured too: no change,
+// the masked passes cost almost nothing next to the atomics; removed.)
+constexpr int kRayCopies = 8;
 
-struct RunTracker {
-  bool seen = false;
-  // true when the pass just finished (wave-uniform `live` = some lane had an unmasked waypoint) ends the run
-  __device__ __forceinline__ bool done_after(bool live) {
-    if (live) { seen = true; return false; }
-    return seen;
-  }
-};
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
 // logits of the K waypoints owned by this lane
 __device__ __forceinline__ void lane_logits(const float* __restrict__ vol, const Ray& r,
                                             const VolDims& v, float step, int lane,
                                             float (&f)[kPerLane]) {
-#if VIDAR_RAY_EARLY_EXIT
-  RunTracker run;
-  bool done = false;
-#pragma unroll
-  for (int j = 0; j < kPerLane; ++j) {
-    f[j] = kNegInf;
-    if (done) continue;                                  // wave-uniform
-    float sx, sy, sz;
-    waypoint(r, lane + j * kWave, step, sx, sy, sz);
-    const Tri t = make_tri(sx, sy, sz, v);
-    if (!t.masked) f[j] = tri_load(vol, t);
-    done = run.done_after(wave_any(!t.masked));
-  }
-#else
 #pragma unroll
   for (int j = 0; j < kPerLane; ++j) {
     float sx, sy, sz;
@@ -188,7 +153,6 @@ __device__ __forceinline__ void lane_logits(const float* __restrict__ vol, const
     const Tri t = make_tri(sx, sy, sz, v);
     f[j] = t.masked ? kNegInf : tri_load(vol, t);
   }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -241,25 +205,15 @@ __global__ __launch_bounds__(kThreads) void ray_ce_bwd_kernel(
   if (ray.f < 0 || t0.masked) return;
   const size_t slice = (size_t)ray.f * v.Z * v.Y * v.X;
   const float* vol = sigma + slice;
-#if VIDAR_RAY_COPIES > 1
   float* gvol = grad_sigma + (size_t)(blockIdx.x % kRayCopies) * v.F * v.Z * v.Y * v.X + slice;
-#else
-  float* gvol = grad_sigma + slice;
-#endif
   const float lse = lse_in[r];
   if (lane == 0) tri_scatter(gvol, t0, g * (expf(tri_load(vol, t0) - lse) - 1.f));
   const int cx = lane & 1;
-#if VIDAR_RAY_EARLY_EXIT
-  RunTracker run;
-#endif
   for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
     float sx, sy, sz;
     waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
     const Tri t = make_tri(sx, sy, sz, v);
     if (!t.masked) tri_scatter_x(gvol, t, g * expf(tri_load(vol, t) - lse), cx);
-#if VIDAR_RAY_EARLY_EXIT
-    if (run.done_after(wave_any(!t.masked))) break;
-#endif
   }
 }
 
@@ -334,27 +288,9 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
   if (ray.f < 0) return;
   const size_t slice = (size_t)ray.f * v.Z * v.Y * v.X;
   const float* vol = sigma + slice;
-#if VIDAR_RAY_COPIES > 1
   float* gvol = grad_sigma + (size_t)(blockIdx.x % kRayCopies) * v.F * v.Z * v.Y * v.X + slice;
-#else
-  float* gvol = grad_sigma + slice;
-#endif
   const float pd = aux[(size_t)r * 3 + 0], pn = aux[(size_t)r * 3 + 1], lse = aux[(size_t)r * 3 + 2];
   const int cx = lane & 1;
-#if VIDAR_RAY_EARLY_EXIT
-  RunTracker run;
-  for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
-    float sx, sy, sz;
-    waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
-    const Tri t = make_tri(sx, sy, sz, v);
-    if (!t.masked) {
-      const float p = expf(tri_load(vol, t) - lse);
-      const float ind = dist_to(ray, sx, sy, sz) > pd ? 1.f : 0.f;
-      tri_scatter_x(gvol, t, g * pd * p * (ind - pn), cx);
-    }
-    if (run.done_after(wave_any(!t.masked))) break;
-  }
-#else
   for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
     float sx, sy, sz;
     waypoint(ray, (lane >> 1) + j * (kWave / 2), step, sx, sy, sz);
@@ -364,7 +300,6 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
     const float ind = dist_to(ray, sx, sy, sz) > pd ? 1.f : 0.f;
     tri_scatter_x(gvol, t, g * pd * p * (ind - pn), cx);
   }
-#endif
 }
 
 // test-time decode: exact zeros are masked to -inf (:728), arg-max waypoint -> distance
@@ -412,7 +347,6 @@ inline dim3 rm_grid(int R) { return dim3((R + kRaysPerBlock - 1) / kRaysPerBlock
 
 }  // namespace
 
-#if VIDAR_RAY_COPIES > 1
 namespace {
 __global__ __launch_bounds__(256) void ray_sum_copies_kernel(const float* __restrict__ copies, float* __restrict__ out,
                                                              size_t n) {
@@ -434,7 +368,6 @@ inline float* ray_scratch(size_t floats) {
   return g_ray_scratch;
 }
 }  // namespace
-#endif
 
 extern "C" {
 
@@ -461,7 +394,6 @@ int vidar_ray_ce_bwd_f32(const float* sigma, const float* origin, const float* g
   if (e != hipSuccess) return (int)e;
   if (R == 0) return 0;
   VolDims v{F, Z, Y, X};
-#if VIDAR_RAY_COPIES > 1
   const size_t n = (size_t)F * Z * Y * X;
   float* sc = ray_scratch(n * kRayCopies);
   if (!sc) return (int)hipErrorOutOfMemory;
@@ -470,10 +402,6 @@ int vidar_ray_ce_bwd_f32(const float* sigma, const float* origin, const float* g
   hipLaunchKernelGGL(ray_ce_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, gt_pts, tindex, lse, grad_ce,
                      sc, R, v, step);
   hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc, grad_sigma, n);
-#else
-  hipLaunchKernelGGL(ray_ce_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, gt_pts,
-                     tindex, lse, grad_ce, grad_sigma, R, v, step);
-#endif
   return vidar_last_error();
 }
 
@@ -500,7 +428,6 @@ int vidar_ray_gumbel_bwd_f32(const float* sigma, const float* origin, const floa
   if (e != hipSuccess) return (int)e;
   if (R == 0) return 0;
   VolDims v{F, Z, Y, X};
-#if VIDAR_RAY_COPIES > 1
   const size_t n = (size_t)F * Z * Y * X;
   float* sc = ray_scratch(n * kRayCopies);
   if (!sc) return (int)hipErrorOutOfMemory;
@@ -509,10 +436,6 @@ int vidar_ray_gumbel_bwd_f32(const float* sigma, const float* origin, const floa
   hipLaunchKernelGGL(ray_gumbel_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, pts, tindex, aux,
                      grad_dist, sc, R, v, step);
   hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc, grad_sigma, n);
-#else
-  hipLaunchKernelGGL(ray_gumbel_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, pts,
-                     tindex, aux, grad_dist, grad_sigma, R, v, step);
-#endif
   return vidar_last_error();
 }
 

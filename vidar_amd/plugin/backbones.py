@@ -202,41 +202,10 @@ class FrozenBN(nn.BatchNorm2d):
         return _AffineAct.apply(x, scale, shift, residual, relu)
 
 
-def stem_conv_space_to_depth(conv, x):
-    """conv1 of the stem (7x7, stride 2, padding 3, 3 input channels) as a 4x4 stride-1 convolution over the 2x2
-    space-to-depth image (12 channels): out[y, x] = sum_{u,v in -3..3} w[u+3, v+3] in[2y+u, 2x+v], and row 2y+u of
-    the image is row y + floor(u/2) of plane (u mod 2) of the rearranged one, so the 7 row taps become 4 (offsets
-    -2..1, the (-2, plane 0) one empty) -- 30 % more multiply-adds in exchange for a stride-1 problem with 12 instead
-    of 3 input channels.  Same products, summed in a different order.  Staged (VIDAR_STEM_S2D=1): whether MIOpen runs
-    it faster than the 34 TFLOP/s of the 7x7 form has to be measured.  None when it does not apply."""
-    if conv.kernel_size != (7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3) or conv.bias is not None \
-            or conv.groups != 1 or x.shape[-1] % 2 or x.shape[-2] % 2 or conv.weight.requires_grad:
-        return None
-    key = (conv.weight._version, conv.weight.device)
-    cache = conv.__dict__.get("_s2d_weight")
-    if cache is None or cache[0] != key:
-        w = conv.weight.detach()
-        co, ci = w.shape[:2]
-        w2 = w.new_zeros(co, ci, 2, 2, 4, 4)                       # [co, c, p, q, da+2, db+2]
-        for da in range(-2, 2):
-            for p_ in range(2):
-                i = 2 * da + p_ + 3
-                if not 0 <= i < 7:
-                    continue
-                for db in range(-2, 2):
-                    for q_ in range(2):
-                        j = 2 * db + q_ + 3
-                        if 0 <= j < 7:
-                            w2[:, :, p_, q_, da + 2, db + 2] = w[:, :, i, j]
-        cache = (key, w2.reshape(co, ci * 4, 4, 4).contiguous())   # pixel_unshuffle's channel order: c*4 + p*2 + q
-        conv.__dict__["_s2d_weight"] = cache
-    return F.conv2d(F.pad(F.pixel_unshuffle(x, 2), (2, 1, 2, 1)), cache[1])
-
-
 def stem_bn_relu_pool(x, bn):
     """max_pool2d(relu(bn(x)), 3, 2, 1) of the frozen stem in one pass (vidar_stem_bn_relu_pool_f32), or None when
     the fused kernel does not apply (gradients needed, trainable BN, CPU tensor, W % 4 != 0): the caller then takes
-    the two-kernel path.  Staged: only reached with VIDAR_FUSED_STEM=1."""
+    the two-kernel path (bit-identical, tests/test_dcn_gpu.py; 1.3 ms of the step)."""
     if not x.is_cuda or bn.weight.requires_grad or (torch.is_grad_enabled() and x.requires_grad):
         return None
     x = x.float().contiguous()
@@ -394,9 +363,8 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        y = stem_conv_space_to_depth(self.conv1, x) if os.environ.get("VIDAR_STEM_S2D") == "1" else None
-        x = y if y is not None else self.conv1(x)
-        y = stem_bn_relu_pool(x, self.bn1) if os.environ.get("VIDAR_FUSED_STEM") == "1" else None
+        x = self.conv1(x)
+        y = stem_bn_relu_pool(x, self.bn1)
         x = y if y is not None else F.max_pool2d(self.bn1(x, relu=True), 3, stride=2, padding=1)
         outs = []
         for i, name in enumerate(self.res_layers):

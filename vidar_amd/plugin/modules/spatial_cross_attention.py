@@ -120,12 +120,6 @@ class SpatialCrossAttention(nn.Module):
                 plan.ref_re = reference_points_cam.permute(1, 0, 2, 3, 4)[
                     torch.arange(bs, device=idx.device)[:, None, None], cams[None, :, None], idx[None]] \
                     * valid[None, :, :, None, None].to(query.dtype)
-                if os.environ.get("VIDAR_SCA_PAD_NAN") == "1":
-                    # staged (tools/first_gpu_call.sh): a padded slot's anchors are NaN instead of 0, so all its samples
-                    # are "outside" for the MSDA kernels -- output row 0, not sorted into the backward's tiles, zero
-                    # gradients (the kernels' NaN handling is tested: tests/test_msda_gpu.py); the rows are dropped by
-                    # the scatter-back either way.  9.5 % of the rows with the six nuScenes cameras.
-                    plan.ref_re = plan.ref_re.masked_fill(~valid[None, :, :, None, None], float("nan"))
             q_re = _ScaRows.apply(query, plan, False)
             key = key.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)
             value = value.permute(2, 0, 1, 3).reshape(bs * self.num_cams, l, self.embed_dims)

@@ -55,9 +55,9 @@ def build_optimizer(model, lr=2e-4, weight_decay=0.01, backbone_lr_mult=0.1):
     groups = [dict(params=rest)]
     if bb:
         groups.append(dict(params=bb, lr=lr * backbone_lr_mult))
-    # staged, default off (tools/first_gpu_call.sh times it): torch's single-kernel AdamW instead of the foreach
-    # implementation's ~12 elementwise launches per step (same fp32 update, different instruction order)
-    fused = os.environ.get("VIDAR_FUSED_ADAMW") == "1" and all(p.is_cuda for g in groups for p in g["params"])
+    # torch's single-kernel AdamW instead of the foreach implementation's ~12 elementwise launches per step (same fp32
+    # update, different instruction order); VIDAR_FUSED_ADAMW=0 restores the foreach form
+    fused = os.environ.get("VIDAR_FUSED_ADAMW", "1") != "0" and all(p.is_cuda for g in groups for p in g["params"])
     return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, **({"fused": True} if fused else {}))
 
 
