@@ -64,10 +64,15 @@ def parse():
     ap.add_argument("--cpu-baseline-step", action="store_true",
                     help="also time the oracle port of the WHOLE step on a bounded sample (BEV 50x50; round-2 leg)")
     ap.add_argument("--extra-configs",
-                    default="vidar_1_8_nusc_3future,vidar_OpenScene_mini_full_3future,vidar_full_nusc_1future@2",
-                    help="comma-separated `config[@samples_per_gpu]` entries timed after the main one in the same run "
-                         "(short records under `configs`): BASELINE.json's other named configs -- the north star's "
-                         "target sentence names vidar_1_8_nusc_3future; OpenScene = 8 cameras; @2 = per-GPU batch 2")
+                    default="vidar_1_8_nusc_3future,mem_efficient_vidar_1_8_nusc_3future,vidar_OpenScene_mini_full_3future,"
+                            "vidar_1_8_nusc_1future@1:bf16x3,vidar_1_8_nusc_3future@1:bf16x3,"
+                            "vidar_full_nusc_1future@2,vidar_full_nusc_1future@4,vidar_full_nusc_1future@7",
+                    help="comma-separated `config[@samples_per_gpu][:gemm]` entries timed after the main one in the same "
+                         "run (short records under `configs`, each with its peak device memory): BASELINE.json's other "
+                         "named configs -- the north star's target sentence names vidar_1_8_nusc_3future (and the "
+                         "reference's memory-efficient variant of it, README.md:143-148); OpenScene = 8 cameras; "
+                         ":bf16x3 = the split-bf16 MFMA GEMM path (a labelled second record, the headline stays fp32); "
+                         "@2/@4/@7 = per-GPU batch sweep of config c3 (\"per-GPU batch sized to 288 GB\")")
     ap.add_argument("--gemm", choices=["lib", "auto", "f32", "bf16x3"], default=None,
                     help="what the Linear / 1x1-convolution products of the main record run on (default: vidar_amd.gemm."
                          "mode(), i.e. $VIDAR_GEMM or the package default); extra configs take it as `name@spg:gemm`")

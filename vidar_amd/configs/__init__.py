@@ -22,6 +22,14 @@ VARIANTS = {
                                    backward_prev=0, drop_prev=(0.0, None), img_hw=(928, 1600),
                                    data=dict(rand_frame_interval=(-1, 1, 2), load_frame_interval=8, voxel_size=1.0,
                                              future_test=6)),
+    # nusc_1_8_subset/mem_efficient_vidar_1_8_nusc_3future.py (README.md:143-148: ~34 GB instead of ~63 GB on an A100):
+    # only the last future frame is supervised, the head predicts the current frame only, LatentRendering step 1.0
+    "mem_efficient_vidar_1_8_nusc_3future": dict(future=3, dec_layers=3, lr_step=1.0, hist_pred=0, fut_pred=0,
+                                                 slice_w=(1.0,), cams=6, future_frames=4,
+                                                 backward_prev=0, drop_prev=(0.0, None), img_hw=(928, 1600),
+                                                 supervise_all_future=False,
+                                                 data=dict(rand_frame_interval=(-1, 1), load_frame_interval=8,
+                                                           voxel_size=1.0, future_test=6)),
     "vidar_full_nusc_1future": dict(future=0, dec_layers=1, lr_step=0.5, hist_pred=3, fut_pred=1,
                                     slice_w=(0.2, 0.4, 0.6, 1.0, 1.2), cams=6, future_frames=1,
                                     backward_prev=1, drop_prev=(0.1, 3), img_hw=(928, 1600),
@@ -89,7 +97,7 @@ def model_config(name, bev_h=200, bev_w=200, with_backbone=False):
                     positional_encoding=dict(pos))
     model = dict(type="ViDAR", use_grid_mask=True, video_test_mode=True, point_cloud_range=PC_RANGE,
                  bev_h=bev_h, bev_w=bev_w, future_pred_frame_num=n_fut, test_future_frame_num=n_fut * 2,
-                 supervise_all_future=True, random_drop_prev_rate=v["drop_prev"][0],
+                 supervise_all_future=v.get("supervise_all_future", True), random_drop_prev_rate=v["drop_prev"][0],
                  random_drop_prev_end_idx=v["drop_prev"][1],
                  backwarded_prev_frame_num=v["backward_prev"], future_pred_head=head,
                  pts_bbox_head=bev_head)
