@@ -66,16 +66,19 @@ def parse():
     ap.add_argument("--extra-configs",
                     default="vidar_1_8_nusc_3future,mem_efficient_vidar_1_8_nusc_3future,vidar_OpenScene_mini_full_3future,"
                             "vidar_1_8_nusc_1future@1:bf16x3,vidar_1_8_nusc_3future@1:bf16x3,"
-                            "vidar_full_nusc_1future@2,vidar_full_nusc_1future@4,vidar_full_nusc_1future@7",
+                            "vidar_full_nusc_1future@2,vidar_full_nusc_1future@4",
                     help="comma-separated `config[@samples_per_gpu][:gemm]` entries timed after the main one in the same "
                          "run (short records under `configs`, each with its peak device memory): BASELINE.json's other "
                          "named configs -- the north star's target sentence names vidar_1_8_nusc_3future (and the "
                          "reference's memory-efficient variant of it, README.md:143-148); OpenScene = 8 cameras; "
                          ":bf16x3 = the split-bf16 MFMA GEMM path (a labelled second record, the headline stays fp32); "
-                         "@2/@4/@7 = per-GPU batch sweep of config c3 (\"per-GPU batch sized to 288 GB\")")
+                         "@2/@4 = per-GPU batch sweep of config c3 (\"per-GPU batch sized to 288 GB\")")
     ap.add_argument("--gemm", choices=["lib", "auto", "f32", "bf16x3"], default=None,
                     help="what the Linear / 1x1-convolution products of the main record run on (default: vidar_amd.gemm."
                          "mode(), i.e. $VIDAR_GEMM or the package default); extra configs take it as `name@spg:gemm`")
+    ap.add_argument("--extra-budget-s", type=float, default=240.0,
+                    help="wall-clock budget of the extra configs together: entries that would start after it are recorded "
+                         "as skipped (the contract line must appear within minutes)")
     ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--extra-warmup", type=int, default=2)
     ap.add_argument("--cpu-baseline-only", choices=["ops", "step", "full"], help=argparse.SUPPRESS)
@@ -465,13 +468,17 @@ def make_batch(cfg, args, rank, dev, spg=None):
     return batch
 
 
-def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, gemm_mode=None):
+def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, gemm_mode=None, tune=True):
     """build the model of one named config, time `steps` training steps -> dict(elapsed, ops, ddp, cfg, peak_mem_gb)"""
     from vidar_amd import gemm as G
     prev = G.set_mode(gemm_mode or G.mode())
     try:
         torch.cuda.reset_peak_memory_stats(dev)
-        r = _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg)
+        t0 = time.perf_counter()
+        r = _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg, tune)
+        if rank == 0:
+            print(f"[bench] {name} spg={spg or args.samples_per_gpu} gemm={G.mode()}: {r['elapsed'] / steps * 1e3:.1f} ms/step "
+                  f"({time.perf_counter() - t0:.0f} s wall incl. build + warm-up)", file=sys.stderr, flush=True)
         r["gemm"] = G.mode()
         # the number next to the reference's only published figure for this path (README.md:143-148: ~63 GB for
         # vidar_1_8_nusc_3future, ~34 GB for its memory-efficient variant, per A100)
@@ -486,7 +493,7 @@ GEMM_DTYPE = {"lib": "f32", "auto": "f32", "f32": "f32",
               "bf16x3": "f32 storage, bf16x3 MFMA products (16-bit significand >= TF32), f32 accumulate"}
 
 
-def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None):
+def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, tune=True):
     from vidar_amd import gemm_tuning
     from vidar_amd import train as T
     from vidar_amd._lib import TIMER
@@ -508,7 +515,12 @@ def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers
         TIMER.reset()
         TIMER.enabled = True
 
-    gemm_tuning.thaw()
+    # only the main record tunes GEMM shapes it has not seen (the shipped solutions cover it); an extra config with new
+    # shapes (a larger per-GPU batch) would spend minutes trying hundreds of library solutions per shape
+    if tune:
+        gemm_tuning.thaw()
+    else:
+        gemm_tuning.freeze()
     elapsed = timed_steps(lambda: T.train_step(ddp, opt, batch, cfg["grad_clip"]), steps, warmup, grouped, True,
                           after_warmup=after_warmup,
                           markers=(lambda k: _hip().vidar_marker(k, None)) if with_markers else None)
@@ -553,6 +565,7 @@ def main():
                           gemm_mode=args.gemm)
     elapsed, ops, cfg = main_run["elapsed"], main_run["ops"], main_run["cfg"]
     extras = []
+    t_extras = time.perf_counter()
     for entry in [c for c in args.extra_configs.split(",") if c]:
         head, _, xgemm = entry.partition(":")
         name, _, xs = head.partition("@")
@@ -561,11 +574,18 @@ def main():
         if name == args.config and xspg == spg and (xgemm or main_run["gemm"]) == main_run["gemm"]:
             continue
         # an extra config must never cost the main measurement its record: a failure (e.g. out of memory at a large
-        # per-GPU batch) is agreed on across ranks and written into the entry
+        # per-GPU batch) is agreed on across ranks and written into the entry; so is running out of the time budget
         err = None
+        over = torch.tensor([1.0 if time.perf_counter() - t_extras > args.extra_budget_s else 0.0], device=dev)
+        if grouped:
+            dist.all_reduce(over, op=dist.ReduceOp.MAX)
+        if float(over) > 0:
+            extras.append({"config": name, "samples_per_gpu": xspg, "gemm": xgemm or main_run["gemm"],
+                           "skipped": f"extra-config time budget ({args.extra_budget_s:.0f} s) spent"})
+            continue
         try:
             r = run_config(name, args, rank, local, world, dev, args.extra_steps, args.extra_warmup, with_markers=False,
-                           spg=xspg, gemm_mode=xgemm)
+                           spg=xspg, gemm_mode=xgemm, tune=False)
         except Exception as e:                                              # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
             r = None
@@ -642,6 +662,7 @@ def main():
         # the two auxiliary legs run after the timed region; a failure in one of them is reported in the line
         # (and on stderr) instead of costing the measured throughput its record
         if world == 1 and not args.no_kernel_rooflines and not grouped:
+            print("[bench] kernel rooflines ...", file=sys.stderr, flush=True)
             try:
                 out["roofline_kernels"] = kernel_rooflines(dev)
             except Exception as e:                                          # noqa: BLE001
@@ -649,6 +670,7 @@ def main():
                 traceback.print_exc()
                 out["roofline_kernels_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline and not grouped:
+            print("[bench] cpu baseline (child process) ...", file=sys.stderr, flush=True)
             try:
                 out["cpu_baseline"] = cpu_baseline_record(args, ops, args.steps, out.get("roofline_kernels"))
             except Exception as e:                                          # noqa: BLE001
