@@ -251,8 +251,9 @@ def cpu_baseline_ops(threads):
     add("dvxlr.render[M=30000]", _once_or_twice(lambda: O.dvxlr_render(sig, origin, points, tindex)), "30000 rays, volume 16x200x200", dvr_impl)
     add("dvr.render_forward[M=30000]", _once_or_twice(lambda: O.render_forward(sig, origin, points, tindex, "train")), "same", dvr_impl)
     add("dvr.render[M=30000]", _once_or_twice(lambda: O.render(sig, origin, points, tindex, "l1")), "same", dvr_impl)
-    # second column: the rows that scale with cores (OpenMP over rays; the MSDA formula over torch's intra-op pool) on
-    # ALL host cores (BASELINE.md section 3 asks for the box's cores; `threads` = 16 is where the torch rows stop scaling)
+    # second column: the rows that scale with cores (OpenMP over rays) on ALL host cores (BASELINE.md section 3 asks
+    # for the box's cores; `threads` = 16 is where the torch rows stop scaling -- the MSDA formula on 256 torch threads
+    # measured 5 x SLOWER than on 16, profiles/r04_bench_driver_like.json of the first try, so it is not repeated)
     allc = os.cpu_count() or threads
     if allc > threads:
         by = {r["op"]: r for r in rows}
@@ -262,11 +263,6 @@ def cpu_baseline_ops(threads):
                        ("dvr.render[M=30000]", lambda: O.render(sig, origin, points, tindex, "l1"))):
             by[op]["cpu_ms_all_cores"] = round(_once_or_twice(fn) * 1e3, 2)
         O.set_threads(threads)
-        torch.set_num_threads(allc)
-        value, sh, lsi, loc, w = msda_operands(0, 6, fpn, 10000, P=8)
-        with torch.no_grad():
-            by["msda_fwd[L=4,P=8]"]["cpu_ms_all_cores"] = round(_once_or_twice(lambda: M.msda_grid_sample(value, sh, loc, w)) * 1e3, 2)
-        torch.set_num_threads(threads)
     return dict(ops=rows, cores=threads, all_cores=allc)
 
 

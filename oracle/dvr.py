@@ -36,7 +36,14 @@ def _f(a):
 
 
 def set_threads(n: int):
+    """OpenMP threads of the C restatement.  The environment variable only counts before libgomp starts, so the
+    runtime the library is linked against is told directly as well."""
     os.environ["OMP_NUM_THREADS"] = str(n)
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
 
 
 def _dims(sigma, origin, points):
