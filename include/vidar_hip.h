@@ -163,6 +163,11 @@ int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
  *                       call) and must stay alive until the stream has run the call.
  * Both give the same result up to fp32 summation order. */
 size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P);
+/* tuning/A-B switch of the gather kernels (forward, grad_loc / grad_w): which 32 (batch, query, head) items a workgroup
+ * owns.  1 (default) = head-major: 32 consecutive queries of ONE head, head = workgroup % H, so that with ViDAR's 8 heads
+ * each of the 8 XCDs only reads its own head's plane of `value` (it fits the XCD's 4 MiB L2); 0 = 4 queries x 8 heads in
+ * contiguous query bands per XCD (rounds 1-3).  Results do not depend on it.  Returns the previous value. */
+int vidar_msda_set_item_order(int head_major);
 int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, const float* grad_out, float* grad_value,

@@ -8,6 +8,16 @@ from oracle import msda as M
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["head_major", "banded"])
+def item_order(request):
+    """every case under both workgroup -> item orders of the gather kernels (vidar_msda_set_item_order): results must not
+    depend on which 32 (batch, query, head) items a workgroup owns"""
+    from vidar_amd._lib import lib
+    prev = lib().vidar_msda_set_item_order(1 if request.param == "head_major" else 0)
+    yield request.param
+    lib().vidar_msda_set_item_order(prev)
+
 CASES = [
     ("tsa_small", 2, [(20, 20)], 400, 4),
     ("sca_small", 3, [(12, 20), (6, 10), (3, 5), (2, 3)], 333, 8),

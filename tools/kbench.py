@@ -335,6 +335,10 @@ def bench_gemm_pmc(which):
 
 
 if __name__ == "__main__":
+    import os
+    if os.environ.get("VIDAR_MSDA_ITEM_ORDER") is not None:          # A/B of the gather kernels' item order (0 banded, 1 head-major)
+        from vidar_amd._lib import lib
+        lib().vidar_msda_set_item_order(int(os.environ["VIDAR_MSDA_ITEM_ORDER"]))
     which = sys.argv[1:] or ["dvr", "knn", "msda", "lr", "ray"]
     print(json.dumps({"device": torch.cuda.get_device_name(0)}))
     for w in which:

@@ -45,6 +45,35 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return (bid & 7) * per + (bid >> 3);
 }
 
+// Which 32 (b, q, head) items a workgroup of the gather kernels owns.
+//   banded (round 1-3): 32 consecutive items = 4 queries x 8 heads, XCD k walks the k-th contiguous band of queries.
+//     Every wave then touches all 8 head planes of `value`: the working set of an XCD's 4 MiB L2 is 8 planes wide and
+//     the counters show it -- SpatialCrossAttention fetches the 189 MB `value` tensor 16 x from HBM, L2 hit rate 46-53 %.
+//   head-major: 32 consecutive (b, q) pairs of ONE head, head = blockIdx % H.  Workgroups are dealt round-robin to the
+//     8 XCDs, so with the 8 heads of ViDAR XCD k only ever reads head k's plane (3.9 MB per camera at the FPN sizes:
+//     it fits the XCD's L2) and all XCDs walk the queries at the same pace.
+// item(it) = base + it * stride covers both; `vidar_msda_set_item_order` switches (A/B, results are identical).
+struct ItemMap {
+  int64_t base;
+  int stride, nvalid;
+  __device__ __forceinline__ int64_t at(int it) const { return base + (int64_t)it * stride; }
+};
+
+__device__ __forceinline__ bool item_map(ItemMap& m, int bid, int nblocks, int64_t n_items, int H, int head_major) {
+  if (head_major) {
+    const int64_t BQ = n_items / H;
+    const int h = bid % H;
+    const int64_t bq0 = (int64_t)(bid / H) * kItems;
+    if (bq0 >= BQ) return false;
+    m.base = bq0 * H + h; m.stride = H; m.nvalid = (int)min((int64_t)kItems, BQ - bq0);
+    return true;
+  }
+  const int blk = xcd_remap(bid, nblocks);
+  if (blk >= nblocks) return false;
+  m.base = (int64_t)blk * kItems; m.stride = 1; m.nvalid = (int)min((int64_t)kItems, n_items - m.base);
+  return true;
+}
+
 // pixel coordinate of a normalised location: ONE rounding (fma), the same in every kernel -- the
 // binned backward computes the tile of a sample in one kernel and its window offset in another
 __device__ __forceinline__ float pix(float v, int n) { return __fmaf_rn(v, (float)n, -0.5f); }
@@ -138,25 +167,27 @@ __device__ __forceinline__ void load_levels(GLevels& t, const int64_t* __restric
   }
 }
 
-// stage (x, y, w) of `nvalid` items starting at item0 into fields 0..2 of their records
+// stage (x, y, w) of the workgroup's items into fields 0..2 of their records
 template <int kThr>
 __device__ __forceinline__ void stage_records(const Prep& pr, const float* __restrict__ loc,
                                               const float* __restrict__ attw, const GLevels& lv, float* rec,
-                                              int64_t item0, int nvalid, int H, int Nq, int L, int P) {
+                                              const ItemMap& im, int H, int Nq, int L, int P) {
   const int LP = L * P;
+  const int nvalid = im.nvalid;
   if (pr.off_raw == nullptr) {
     for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
       const int it = i / LP, lp = i - it * LP;
-      const float2 xy = reinterpret_cast<const float2*>(loc)[item0 * LP + i];
+      const int64_t e = im.at(it) * LP + lp;
+      const float2 xy = reinterpret_cast<const float2*>(loc)[e];
       float* r = rec + rec_at(it, lp, LP);
-      r[0] = xy.x; r[1] = xy.y; r[2] = attw[item0 * LP + i];
+      r[0] = xy.x; r[1] = xy.y; r[2] = attw[e];
     }
     __syncthreads();
     return;
   }
   for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
     const int it = i / LP, lp = i - it * LP;
-    const int64_t item = item0 + it;
+    const int64_t item = im.at(it);
     const int64_t raw = raw_index(item, lp, H, Nq, LP, pr.Qn);
     const int l = lp / P, p = lp - l * P;
     const int rr = pr.mode == 0 ? l : p % pr.R;
@@ -202,21 +233,23 @@ __device__ __forceinline__ void stage_records(const Prep& pr, const float* __res
     for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
       const int it = i / LP, lp = i - it * LP;
       const float* r = rec + rec_at(it, lp, LP);
-      reinterpret_cast<float2*>(pr.loc_out)[item0 * LP + i] = make_float2(r[0], r[1]);
-      pr.w_out[item0 * LP + i] = r[2];
+      const int64_t e = im.at(it) * LP + lp;
+      reinterpret_cast<float2*>(pr.loc_out)[e] = make_float2(r[0], r[1]);
+      pr.w_out[e] = r[2];
     }
   }
 }
 
 // corner arithmetic of one sample, once: (x, y, w) in the record -> the forward or backward record
 template <int kThr, bool BWD>
-__device__ __forceinline__ void corner_records(const GLevels& lv, float* rec, int64_t item0, int nvalid, int Nv,
+__device__ __forceinline__ void corner_records(const GLevels& lv, float* rec, const ItemMap& im, int Nv,
                                                int H, int Nq, int L, int P) {
   const int LP = L * P;
+  const int nvalid = im.nvalid;
   for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
     const int it = i / LP, lp = i - it * LP;
     const int l = lp / P;
-    const int64_t item = item0 + it;
+    const int64_t item = im.at(it);
     const int h = (int)(item % H);
     const int b = (int)(item / H / Nq);
     const int Hl = lv.Hl[l], Wl = lv.Wl[l];
@@ -252,18 +285,18 @@ __device__ __forceinline__ float4 ldv(const float* __restrict__ value, unsigned 
 __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
-    float* __restrict__ out, int Nv, int H, int Nq, int L, int P, int64_t n_items, int nblocks, Prep pr) {
+    float* __restrict__ out, int Nv, int H, int Nq, int L, int P, int64_t n_items, int nblocks, int head_major,
+    Prep pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ GLevels lv;
   const int LP = L * P;
-  const int blk = xcd_remap(blockIdx.x, nblocks);
-  if (blk >= nblocks) return;
+  ItemMap im;
+  if (!item_map(im, blockIdx.x, nblocks, n_items, H, head_major)) return;
   load_levels(lv, shapes, lsi, L);
   __syncthreads();
-  const int64_t item0 = (int64_t)blk * kItems;
-  const int nvalid = (int)min((int64_t)kItems, n_items - item0);
-  stage_records<kThreads>(pr, loc, attw, lv, smem, item0, nvalid, H, Nq, L, P);
-  corner_records<kThreads, false>(lv, smem, item0, nvalid, Nv, H, Nq, L, P);
+  const int nvalid = im.nvalid;
+  stage_records<kThreads>(pr, loc, attw, lv, smem, im, H, Nq, L, P);
+  corner_records<kThreads, false>(lv, smem, im, Nv, H, Nq, L, P);
   const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
   if (it >= nvalid) return;
   const unsigned sub16 = sub * 16;
@@ -280,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
     acc.z += w.x * v00.z + w.y * v01.z + w.z * v10.z + w.w * v11.z;
     acc.w += w.x * v00.w + w.y * v01.w + w.z * v10.w + w.w * v11.w;
   }
-  *reinterpret_cast<float4*>(out + (item0 + it) * kCh + sub * 4) = acc;
+  *reinterpret_cast<float4*>(out + im.at(it) * kCh + sub * 4) = acc;
 }
 
 // store phase of the backward kernels: s_loc / s_w hold grad_loc / grad_w of `nvalid` items
@@ -747,23 +780,22 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv,
-    int H, int Nq, int L, int P, int64_t n_items, int nblocks, Prep pr) {
+    int H, int Nq, int L, int P, int64_t n_items, int nblocks, int head_major, Prep pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ GLevels lv;
   __shared__ float s_dot[kItems];
   const int LP = L * P;
-  const int blk = xcd_remap(blockIdx.x, nblocks);
-  if (blk >= nblocks) return;
+  ItemMap im;
+  if (!item_map(im, blockIdx.x, nblocks, n_items, H, head_major)) return;
   load_levels(lv, shapes, lsi, L);
   __syncthreads();
-  const int64_t item0 = (int64_t)blk * kItems;
-  const int nvalid = (int)min((int64_t)kItems, n_items - item0);
-  stage_records<kThreads>(Prep{}, loc, attw, lv, smem, item0, nvalid, H, Nq, L, P);     // saved (prepared) operands
-  corner_records<kThreads, true>(lv, smem, item0, nvalid, Nv, H, Nq, L, P);
+  const int nvalid = im.nvalid;
+  stage_records<kThreads>(Prep{}, loc, attw, lv, smem, im, H, Nq, L, P);     // saved (prepared) operands
+  corner_records<kThreads, true>(lv, smem, im, Nv, H, Nq, L, P);
   const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
   if (it < nvalid) {
     const unsigned sub16 = sub * 16;
-    const float4 go = *reinterpret_cast<const float4*>(grad_out + (item0 + it) * kCh + sub * 4);
+    const float4 go = *reinterpret_cast<const float4*>(grad_out + im.at(it) * kCh + sub * 4);
     float* r = smem + rec_at(it, 0, LP);
     // (the DPP reductions are convergent operations, which keeps the compiler from unrolling a loop with a
     //  run-time trip count: unrolled by hand, 16 lines in flight per wave)
@@ -791,8 +823,9 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
       gy = w * lv.Hl[l] * (-hw * d00 - lw * d01 + hw * d10 + lw * d11);
     }
     if (!fused) {
-      reinterpret_cast<float2*>(grad_loc)[item0 * LP + i] = make_float2(gx, gy);
-      grad_w[item0 * LP + i] = gw;
+      const int64_t e = im.at(itx) * LP + lp;
+      reinterpret_cast<float2*>(grad_loc)[e] = make_float2(gx, gy);
+      grad_w[e] = gw;
     } else {
       reinterpret_cast<float4*>(r)[0] = make_float4(gx, gy, gw, a.z);
     }
@@ -812,7 +845,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
   for (int i = threadIdx.x; i < nvalid * LP; i += kThreads) {
     const int itx = i / LP, lp = i - itx * LP;
     const float4 a = reinterpret_cast<const float4*>(smem + rec_at(itx, lp, LP))[0];
-    const int64_t raw = raw_index(item0 + itx, lp, H, Nq, LP, pr.Qn);
+    const int64_t raw = raw_index(im.at(itx), lp, H, Nq, LP, pr.Qn);
     const int l = lp / P;
     pr.g_logit_raw[raw] = a.w * (a.z - s_dot[itx]);
     reinterpret_cast<float2*>(pr.g_off_raw)[raw] = make_float2(a.x / (float)lv.Wl[l], a.y / (float)lv.Hl[l]);
@@ -850,9 +883,28 @@ inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
   return B < 0 || Nv < 0 || H <= 0 || C != kCh || Nq < 0 || L <= 0 || P <= 0 || L * P > kMaxLP;
 }
 
+int g_head_major = 1;          // item order of the gather kernels (see ItemMap); vidar_msda_set_item_order
+
+// grid of a gather kernel: banded -- blocks of 32 items, padded to the 8 XCDs; head-major -- blocks of 32 (b, q) pairs x H
+inline void gather_grid(int64_t n_items, int H, int& nblocks, int& grid) {
+  if (g_head_major) {
+    nblocks = (int)((n_items / H + kItems - 1) / kItems) * H;
+    grid = nblocks;
+  } else {
+    nblocks = (int)((n_items + kItems - 1) / kItems);
+    grid = ((nblocks + 7) / 8) * 8;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int vidar_msda_set_item_order(int head_major) {
+  const int prev = g_head_major;
+  g_head_major = head_major ? 1 : 0;
+  return prev;
+}
 
 static int msda_fwd_launch(const float* value, const int64_t* spatial_shapes,
                            const int64_t* level_start_index, const float* sampling_loc,
@@ -861,12 +913,12 @@ static int msda_fwd_launch(const float* value, const int64_t* spatial_shapes,
   if (msda_bad(B, Nv, H, C, Nq, L, P)) return VIDAR_ERR_BAD_ARG;
   const int64_t n_items = (int64_t)B * Nq * H;
   if (n_items == 0) return 0;
-  const int nblocks = (int)((n_items + kItems - 1) / kItems);
-  const int grid = ((nblocks + 7) / 8) * 8;
+  int nblocks, grid;
+  gather_grid(n_items, H, nblocks, grid);
   const size_t lds = rec_lds_bytes(L * P);
   hipLaunchKernelGGL(msda_fwd_kernel, dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, Nv, H, Nq, L,
-                     P, n_items, nblocks, pr);
+                     P, n_items, nblocks, g_head_major, pr);
   return vidar_last_error();
 }
 
@@ -909,12 +961,12 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
                        Nv, H, L, P, (int)(n_items * kCh * 4));
-    const int nblocks = (int)((n_items + kItems - 1) / kItems);
-    const int grid = ((nblocks + 7) / 8) * 8;
+    int nblocks, grid;
+    gather_grid(n_items, H, nblocks, grid);
     const size_t lds = rec_lds_bytes(L * P);
     hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
-                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
+                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, g_head_major, pr);
     return vidar_last_error();
   }
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
