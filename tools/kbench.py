@@ -146,6 +146,19 @@ def bench_msda_sca(which):
     report("msda_bwd SCA binned=True", timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=True), warm=1, it=3))
 
 
+def bench_msda_sca_coherent(which):
+    """SpatialCrossAttention shape on spatially COHERENT queries (neighbouring queries sample 8 level-0 pixels apart: what
+    the model's projected BEV pillars look like), few iterations: the driver of the PMC passes whose traffic is paired
+    with the in-model kernel time in bench.py's `roofline.traffic`"""
+    from vidar_amd.synthetic import msda_operands_coherent
+    from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_backward, _msda_forward
+    fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
+    value, sh, lsi, loc, w = msda_operands_coherent(0, 6, fpn, 10000, P=8, px=8.0, device="cuda")
+    go = torch.randn(6, 10000, 256, device="cuda")
+    report("msda_fwd SCA coherent", timeit(lambda: _msda_forward(value, sh, lsi, loc, w), warm=1, it=3))
+    report("msda_bwd SCA coherent binned=True", timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=True), warm=1, it=3))
+
+
 def bench_dcn(which):
     """DCNv2 sampling kernels at the two backbone shapes (stage 3: 256 ch 58x100, stage 4: 512 ch 29x50),
     12 images = the frames that carry gradients."""

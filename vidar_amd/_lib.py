@@ -3,6 +3,7 @@ fails the product raises, it never routes to a CPU/eager path."""
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -26,6 +27,9 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m vidar_amd.build` "
                 f"(or __graft_entry__.build()); vidar_amd has no CPU fallback")
         _lib = ctypes.CDLL(str(LIB_PATH))
+        order = os.environ.get("VIDAR_MSDA_ITEM_ORDER")          # A/B of the MSDA gather kernels' item order (tools, bench)
+        if order is not None:
+            _lib.vidar_msda_set_item_order(int(order))
     return _lib
 
 
