@@ -110,6 +110,18 @@ def test_batched_and_reduced(precision):
     assert torch.equal(gw, gw2), "the slab reduction must be deterministic"
 
 
+@pytest.mark.parametrize("precision", [G.F32, G.BF16X3])
+@pytest.mark.parametrize("rows,N,K", [(5000, 37, 5), (4099, 3, 3), (70000, 130, 66)])
+def test_split_k_weight_gradient_with_ragged_sizes(precision, rows, N, K):
+    """g^T x over many rows (split over the rows, slabs summed in a fixed order), output sizes that are not multiples
+    of anything: the slab reduction's float4 body and its scalar tail"""
+    g, x = rnd(rows, N, seed=21), rnd(rows, K, seed=22)
+    gw = G.linear_grad_weight(g, x, precision)
+    ref = g.double().t() @ x.double()
+    assert normwise(gw, ref) <= (3e-6 if precision == G.F32 else 8e-5)
+    assert torch.equal(gw, G.linear_grad_weight(g, x, precision))
+
+
 @pytest.mark.parametrize("M,K,N", [(184950, 256, 256), (80000, 256, 256), (40000, 512, 128)])
 def test_bf16x3_at_least_four_times_tighter_than_tf32_at_baseline_shapes(M, K, N):
     """the acceptance criterion of the bf16x3 path: max error vs the fp64 product <= 1/4 of the error of the same

@@ -17,14 +17,14 @@
 //   K-major : the contraction index is contiguous   (x [M,K] of F.linear; weight [N,K] as B)
 //   MN-major: the row / column index is contiguous  (NCHW activations [C, H*W] as B; grad_out^T as A)
 //
-// Tile: 128 x 128 x (32 | 16) per 256-thread workgroup, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of
+// Tile: 128 x 128 x 32 per 256-thread workgroup, 4 waves as 2 x 2, each wave 64 x 64 = 2 x 2 MFMA tiles of
 // 32 x 32 (64 accumulator registers).  Staging is global -> registers -> (split) -> LDS with the next k-tile's global
-// loads in flight under the MFMAs.  LDS images, identical geometry in both modes (a "unit" is one dword = one fp32
-// k or one bf16 k-pair):
-//   K-major  operand: [128 rows][16 units + 4 pad]   row stride 80 B: ds_read_b128 fragments are conflict free
-//                     (slot stride 5 is odd, and each of the instruction's four 16-lane groups covers all 16
+// loads in flight under the MFMAs.  LDS images (a "unit" is one dword = one fp32 k or one bf16 k-pair; U = 32 units per
+// k-step in fp32 mode, 16 in bf16 mode):
+//   K-major  operand: [128 rows][U units + 4 pad]    row stride 144 / 80 B: ds_read_b128 fragments are conflict free
+//                     (slot stride 9 / 5 is odd, and each of the instruction's four 16-lane groups covers all 16
 //                     residues of the row index)
-//   MN-major operand: [16 units][128 rows + 8 pad]   four ds_read_b32 per fragment, 32 consecutive dwords per group
+//   MN-major operand: [U units][128 rows + 8 pad]    four ds_read_b32 per fragment, 32 consecutive dwords per group
 // A lane's fragment is always the four units 8*s + 4*(lane>>5) + {0..3} of its row -- in bf16 mode they ARE the
 // eight consecutive k of one 32x32x16 operand, in fp32 mode they feed four 32x32x2 MFMAs whose two k slots
 // (lane halves) take units t and 4 + t; both operands use the same assignment, which is all a contraction needs.
@@ -54,10 +54,16 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BM = 128, BN = 128, THREADS = 256;
-constexpr int UNITS = 16;                 // dwords of k per row per k-step
-constexpr int KM_STRIDE = UNITS + 4;      // dwords per row of a K-major image
+constexpr int BK = 32;                    // k per step in both modes
 constexpr int MN_STRIDE = 128 + 8;        // dwords per unit row of an MN-major image
-constexpr int IMG_DWORDS = 128 * KM_STRIDE;   // 2560 >= 16 * 136 = 2176: one size for both kinds
+// geometry of an LDS image per mode: a "unit" is one dword of k = one fp32 k (32 per k-step) or one bf16 k pair (16)
+template <int PREC>
+struct Geo {
+  static constexpr int UNITS = (PREC == 1) ? 16 : 32;
+  static constexpr int KM_STRIDE = UNITS + 4;          // dwords per row of a K-major image: slot stride 5 / 9, both odd
+  static constexpr int IMG_DWORDS = (128 * KM_STRIDE > UNITS * MN_STRIDE) ? 128 * KM_STRIDE : UNITS * MN_STRIDE;
+  static constexpr int NS = UNITS / 8;                 // fragment sub-steps per k-step
+};
 constexpr int PREC_F32 = 0, PREC_BF16X3 = 1;
 constexpr int LAY_K = 0, LAY_MN = 1;
 
@@ -74,21 +80,21 @@ struct GemmArgs {
   int total;       // tiles_m * tiles_n * (batch * splits)
 };
 
-// ---- staging: 16 (fp32 mode: 8) floats per operand per thread ----------------------------------------------------
+// ---- staging: 16 floats per operand per thread ------------------------------------------------------------------------
 template <int PREC>
 struct Staged {               // the registers a thread holds between its global loads and its LDS writes
-  static constexpr int CH = (PREC == PREC_BF16X3) ? 2 : 1;   // chunks of 8 floats
+  static constexpr int CH = 2;                                // chunks of 8 floats: 16 floats per operand per thread
   f32x4 v[CH][2];
 };
 
-// K-major operand: element (row, k) at P[row * ld + k].  The lanes of a wave instruction run along k first: LPR = BK/4
-// lanes x 16 bytes cover the whole k-step of one row (bf16 mode: 8 lanes = one 128-byte line; fp32 mode: 4 lanes = half
-// a line), 64/LPR rows per instruction, so every request is a full contiguous piece (one lane per row, or a pair of
+// K-major operand: element (row, k) at P[row * ld + k].  The lanes of a wave instruction run along k first: LPR = BK/4 = 8
+// lanes x 16 bytes cover the whole k-step of one row (one 128-byte line), 8 rows per instruction, so every request is a
+// full contiguous piece (one lane per row, or a pair of
 // lanes 64 bytes apart, made each dwordx4 touch 32 lines in 16-byte pieces: the kernel was bound by the texture
 // addresser, not by MFMA or HBM).  float4 number i of a thread: row 32*wave + i*(64/LPR) + lane/LPR, k (lane%LPR)*4.
 template <int PREC>
 struct KMap {
-  static constexpr int LPR = (PREC == PREC_BF16X3) ? 8 : 4;     // lanes per row
+  static constexpr int LPR = 8;                                 // lanes per row: 8 x 16 B = the 128-byte k-step of a row
   static constexpr int RPI = 64 / LPR;                          // rows per instruction
   static constexpr int NI = 32 / RPI;                           // instructions (float4 per thread)
 };
@@ -141,7 +147,7 @@ __device__ __forceinline__ void load_kmajor(Staged<PREC>& s, __amdgpu_buffer_rsr
 }
 
 // MN-major operand: element (k, col) at P[k * ld + col].  bf16 mode: item = tid + 256c, column quad item&31, k pair
-// item>>5 (two rows of four columns).  fp32 mode: items tid and tid + 256: column quad item&31, k = item>>5.
+// item>>5 (two rows of four columns).  fp32 mode: items tid + 256 i, i = 0..3: column quad item&31, k = item>>5.
 template <int PREC>
 __device__ __forceinline__ uint32_t voff_mnmajor(int64_t ld, int tid) {
   const int kr = (PREC == PREC_BF16X3) ? (tid >> 5) * 2 : (tid >> 5);
@@ -155,7 +161,7 @@ __device__ __forceinline__ void load_mnmajor(Staged<PREC>& s, __amdgpu_buffer_rs
 #pragma unroll
   for (int i = 0; i < Staged<PREC>::CH * 2; ++i) {
     // uniform k of this load relative to the thread's own row: bf16 mode 16*(i>>1) + (i&1), fp32 mode 8*i
-    const int ku = (PREC == PREC_BF16X3) ? 16 * (i >> 1) + (i & 1) : 8 * i;
+    const int ku = (PREC == PREC_BF16X3) ? 16 * (i >> 1) + (i & 1) : 8 * i;       // i = 0..3 in both modes
     s.v[i >> 1][i & 1] = ld16(rs, voff, (uint32_t)(krel + ku) * (uint32_t)ld * 4u);
   }
 }
@@ -184,10 +190,10 @@ __device__ __forceinline__ void store_kmajor(const Staged<PREC>& s, uint32_t* im
       uint32_t h0, l0, h1, l1;
       split2(v[0], v[1], h0, l0);
       split2(v[2], v[3], h1, l1);
-      *(u32x2*)(img + r * KM_STRIDE + 2 * kq) = u32x2{h0, h1};
-      *(u32x2*)(img + IMG_DWORDS + r * KM_STRIDE + 2 * kq) = u32x2{l0, l1};
+      *(u32x2*)(img + r * Geo<PREC>::KM_STRIDE + 2 * kq) = u32x2{h0, h1};
+      *(u32x2*)(img + Geo<PREC>::IMG_DWORDS + r * Geo<PREC>::KM_STRIDE + 2 * kq) = u32x2{l0, l1};
     } else {                               // (stored as dwords, the type every fragment read uses)
-      *(u32x4*)(img + r * KM_STRIDE + 4 * kq) = __builtin_bit_cast(u32x4, v);
+      *(u32x4*)(img + r * Geo<PREC>::KM_STRIDE + 4 * kq) = __builtin_bit_cast(u32x4, v);
     }
   }
 }
@@ -207,21 +213,21 @@ __device__ __forceinline__ void store_mnmajor(const Staged<PREC>& s, uint32_t* i
         hi[j] = h; lo[j] = l;
       }
       *(u32x4*)(img + u * MN_STRIDE + cq) = hi;
-      *(u32x4*)(img + IMG_DWORDS + u * MN_STRIDE + cq) = lo;
+      *(u32x4*)(img + Geo<PREC>::IMG_DWORDS + u * MN_STRIDE + cq) = lo;
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int item = tid + 256 * i;
-      *(u32x4*)(img + (item >> 5) * MN_STRIDE + (item & 31) * 4) = __builtin_bit_cast(u32x4, s.v[0][i]);
+      *(u32x4*)(img + (item >> 5) * MN_STRIDE + (item & 31) * 4) = __builtin_bit_cast(u32x4, s.v[i >> 1][i & 1]);
     }
   }
 }
 
 // a lane's fragment of row `row` (0..127 inside the tile) for sub-step s: units 8s + 4h + {0..3}
-template <int LAY>
+template <int PREC, int LAY>
 __device__ __forceinline__ u32x4 frag(const uint32_t* img, int row, int s, int h) {
-  if (LAY == LAY_K) return *(const u32x4*)(img + row * KM_STRIDE + 8 * s + 4 * h);
+  if (LAY == LAY_K) return *(const u32x4*)(img + row * Geo<PREC>::KM_STRIDE + 8 * s + 4 * h);
   u32x4 f;
   const uint32_t* p = img + (8 * s + 4 * h) * MN_STRIDE + row;
 #pragma unroll
@@ -271,7 +277,6 @@ __device__ __forceinline__ Tile decode_tile(const GemmArgs& g, int t) {
 template <int PREC, int ALAY, int BLAY>
 __device__ __forceinline__ void fetch(Staged<PREC>& sa, Staged<PREC>& sb, const GemmArgs& g, const Tile& T, int k0, int tid,
                                       uint32_t voa, uint32_t vob) {
-  constexpr int BK = (PREC == PREC_BF16X3) ? 32 : 16;
   const int krel = k0 - T.kbeg;
   const bool tail = k0 + BK > T.kend;
   if (ALAY == LAY_K) load_kmajor<PREC>(sa, T.rsA, g.lda, krel, k0, T.kend, tail, tid, voa);
@@ -285,7 +290,7 @@ template <int PREC, int ALAY, int BLAY>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, Staged<PREC>& sb, const GemmArgs& g,
                                          const Tile& T, uint32_t* imgA, uint32_t* imgB, int tid, uint32_t voa, uint32_t vob) {
   constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
-  constexpr int BK = (PREC == PREC_BF16X3) ? 32 : 16;
+  constexpr int IMG_DWORDS = Geo<PREC>::IMG_DWORDS;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
@@ -295,14 +300,14 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, 
     __syncthreads();
     if (k0 + BK < T.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, T, k0 + BK, tid, voa, vob);   // in flight under the MFMAs below
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < Geo<PREC>::NS; ++s) {
       u32x4 fa[2][IMGS], fb[2][IMGS];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int p = 0; p < IMGS; ++p) {
-          fa[i][p] = frag<ALAY>(imgA + p * IMG_DWORDS, wm + 32 * i + l31, s, h);
-          fb[i][p] = frag<BLAY>(imgB + p * IMG_DWORDS, wn + 32 * i + l31, s, h);
+          fa[i][p] = frag<PREC, ALAY>(imgA + p * IMG_DWORDS, wm + 32 * i + l31, s, h);
+          fb[i][p] = frag<PREC, BLAY>(imgB + p * IMG_DWORDS, wn + 32 * i + l31, s, h);
         }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -395,9 +400,9 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmAr
 template <int PREC, int ALAY, int BLAY>
 __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * IMGS * IMG_DWORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * IMGS * Geo<PREC>::IMG_DWORDS];
   uint32_t* imgA = lds;
-  uint32_t* imgB = lds + IMGS * IMG_DWORDS;
+  uint32_t* imgB = lds + IMGS * Geo<PREC>::IMG_DWORDS;
   const int tid = threadIdx.x;
   const uint32_t voa = ALAY == LAY_K ? voff_kmajor<PREC>(g.lda, tid) : voff_mnmajor<PREC>(g.lda, tid);
   const uint32_t vob = BLAY == LAY_K ? voff_kmajor<PREC>(g.ldb, tid) : voff_mnmajor<PREC>(g.ldb, tid);
@@ -428,17 +433,38 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   }
 }
 
-// C[m, n] = epilogue( sum_z slab[z][m, n] ), slabs summed in z order (deterministic)
+// C[m, n] = epilogue( sum_z slab[z][m, n] ).  64 float4 columns x 4 z-groups per workgroup: a thread sums every fourth
+// slab of its four elements (16-byte loads, Z/4 deep instead of Z), the four partial sums are combined through LDS in
+// z-group order -- the order of the additions is fixed, the result is deterministic.
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __restrict__ ws, int Z, GemmArgs g) {
-  const int64_t total = (int64_t)g.M * g.N;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    float a = 0.0f;
-    for (int z = 0; z < Z; ++z) a += ws[(int64_t)z * total + e];
-    const int m = (int)(e / g.N), n = (int)(e - (int64_t)m * g.N);
-    const int vi = g.vec_axis == 1 ? m : n;
-    float y = a * (g.scale ? g.scale[vi] : 1.0f) + (g.shift ? g.shift[vi] : 0.0f);
-    if (g.residual) y += g.residual[(int64_t)m * g.ldr + n];
-    g.C[(int64_t)m * g.ldc + n] = (g.relu && !(y > 0.0f)) ? 0.0f : y;
+  __shared__ f32x4 part[4][64];
+  const int64_t total = (int64_t)g.M * g.N;                  // a multiple of 4 is NOT required: the tail is scalar
+  const int64_t quads = total >> 2;
+  const int col = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (int64_t q0 = (int64_t)blockIdx.x * 64; q0 < quads + 1; q0 += (int64_t)gridDim.x * 64) {
+    const int64_t q = q0 + col;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (q < quads) {
+      for (int z = zg; z < Z; z += 4) a += *(const f32x4u*)(ws + (int64_t)z * total + 4 * q);
+    } else if (q == quads) {                                 // the last 0..3 elements
+      for (int z = zg; z < Z; z += 4)
+        for (int e = 0; e < (int)(total & 3); ++e) a[e] += ws[(int64_t)z * total + 4 * q + e];
+    }
+    part[zg][col] = a;
+    __syncthreads();
+    if (zg == 0 && q <= quads) {
+      const f32x4 sum = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+      const int n_el = q < quads ? 4 : (int)(total & 3);
+      for (int e = 0; e < n_el; ++e) {
+        const int64_t idx = 4 * q + e;
+        const int m = (int)(idx / g.N), n = (int)(idx - (int64_t)m * g.N);
+        const int vi = g.vec_axis == 1 ? m : n;
+        float y = sum[e] * (g.scale ? g.scale[vi] : 1.0f) + (g.shift ? g.shift[vi] : 0.0f);
+        if (g.residual) y += g.residual[(int64_t)m * g.ldr + n];
+        g.C[(int64_t)m * g.ldc + n] = (g.relu && !(y > 0.0f)) ? 0.0f : y;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -478,7 +504,7 @@ extern "C" {
 
 int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce) {
   if (!reduce) return 1;
-  return pick_splits(M, N, K, batch, precision == PREC_BF16X3 ? 32 : 16);
+  return pick_splits(M, N, K, batch, BK);
 }
 
 size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce) {
@@ -506,7 +532,7 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   if ((a_layout == LAY_MN && (int64_t)K * lda >= (1LL << 29)) || (b_layout == LAY_MN && (int64_t)K * ldb >= (1LL << 29)))
     return VIDAR_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int bk = precision == PREC_BF16X3 ? 32 : 16;
+  const int bk = BK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.sA = strideA; g.sB = strideB; g.sC = strideC;
@@ -535,8 +561,8 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   else launch<PREC_F32>(k, a_layout, b_layout, grid, st);
   if (g.slabs) {
     const int64_t total = (int64_t)M * N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (int)((total / 4 + 1 + 63) / 64);
+    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, Z, g);
   }
   return vidar_last_error();
