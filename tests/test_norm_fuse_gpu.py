@@ -66,7 +66,7 @@ def test_other_widths_take_the_torch_path():
     torch.testing.assert_close(drop_add_layernorm(x, r, norm, 0.5, training=False), norm(x + r))
 
 
-@pytest.mark.parametrize("rows,cols", [(40000, 256), (184950, 256), (46080, 512), (40000, 64), (7, 16), (1, 4), (0, 128),
+@pytest.mark.parametrize("rows,cols", [(40000, 256), (184950, 256), (46080, 512), (40000, 64), (40000, 1024), (7, 16), (1, 4), (0, 128),
                                        (100003, 128)])
 def test_colsum_matches_fp64_column_sums(rows, cols):
     """vidar_colsum_f32: the bias gradient of the Linear layers (sum over rows), against an fp64 sum"""
