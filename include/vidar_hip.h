@@ -216,7 +216,7 @@ size_t vidar_drop_add_ln_bwd_workspace_bytes(int64_t rows); /* scratch for the p
 /* Column sums of a row-major [rows, cols] fp32 matrix: out[c] = sum_r x[r, c] -- the bias gradient of the Linear
  * layers on the path (what autograd computes with a generic `sum(0)` for every nn.Linear the reference's modules
  * own, e.g. temporal_self_attention.py:98-103, spatial_cross_attention.py:66, :244-248, vidar_decoder.py:358-363; mmcv FFN [3P]).  `out` [cols] is
- * zeroed and fully written by the call.  cols must be a multiple of 4 whose quarter is a power of two (<= 1024). */
+ * zeroed and fully written by the call.  cols must be a multiple of 4 whose quarter is a power of two (<= 4096). */
 int vidar_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* stream);
 
 /* ---------------------------------------------------------------------------

@@ -168,13 +168,14 @@ __global__ __launch_bounds__(256) void affine_grad_reduce_kernel(const float* __
 // read as whole coalesced lines, the row lanes of a workgroup meet in LDS and the workgroup adds ONE partial row to the
 // zeroed output (256 workgroups x cols atomics).
 // ---------------------------------------------------------------------------------------------
-constexpr int kColsumThreads = 256;
-constexpr int kColsumIlp = 8;        // rows in flight per thread (16-byte loads): 41 MB in 33 us with two, the kernel was latency bound
+constexpr int kColsumThreads = 1024;
+constexpr int kColsumIlp = 4;        // rows in flight per thread (16-byte loads); at most 256 workgroups: every workgroup ends
+                                     // with `cols` atomics on the same addresses (2 048 small workgroups measured 4 x SLOWER)
 
 __global__ __launch_bounds__(kColsumThreads) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                                 int64_t rows, int cols) {
   __shared__ float4 s_acc[kColsumThreads];
-  const int groups = cols >> 2;                                // float4 column groups, a power of two <= 256
+  const int groups = cols >> 2;                                // float4 column groups, a power of two <= 1024
   const int g = threadIdx.x & (groups - 1), r0 = threadIdx.x / groups, rstep = kColsumThreads / groups;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t row_lo = (int64_t)blockIdx.x * per, row_hi = min(rows, row_lo + per);
@@ -219,7 +220,7 @@ extern "C" {
 
 int vidar_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* stream) {
   VIDAR_ENTER();
-  // cols: a multiple of 4 whose float4 groups are a power of two and fit one workgroup row (4 .. 1024)
+  // cols: a multiple of 4 whose float4 groups are a power of two and fit one workgroup row (4 .. 4096)
   const int groups = cols / 4;
   if (rows < 0 || cols <= 0 || cols % 4 != 0 || (groups & (groups - 1)) != 0 || groups > kColsumThreads)
     return VIDAR_ERR_BAD_ARG;
@@ -228,7 +229,7 @@ int vidar_colsum_f32(const float* x, float* out, int64_t rows, int cols, void* s
   if (e != hipSuccess) return (int)e;
   if (rows == 0) return 0;
   const int64_t rows_per_pass = (int64_t)(kColsumThreads / groups) * kColsumIlp;
-  const int grid = (int)min((int64_t)2048, (rows + rows_per_pass - 1) / rows_per_pass);
+  const int grid = (int)min((int64_t)256, (rows + rows_per_pass - 1) / rows_per_pass);
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)grid), dim3(kColsumThreads), 0, s, x, out, rows, cols);
   return vidar_last_error();
 }

@@ -129,7 +129,7 @@ def linear_grad_weight(g2, x2, precision=F32):
 
 def _colsum(g2):
     n = g2.shape[1]
-    if n % 4 == 0 and (n // 4) & (n // 4 - 1) == 0 and n <= 1024 and g2.data_ptr() % 16 == 0 and g2.is_contiguous():
+    if n % 4 == 0 and (n // 4) & (n // 4 - 1) == 0 and n <= 4096 and g2.data_ptr() % 16 == 0 and g2.is_contiguous():
         gb = torch.empty(n, dtype=torch.float32, device=g2.device)
         check(lib().vidar_colsum_f32(ptr(g2), ptr(gb), ctypes.c_int64(g2.shape[0]), int(n), stream_of(g2)), "colsum")
         return gb

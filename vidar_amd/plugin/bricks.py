@@ -96,7 +96,7 @@ class Linear(nn.Linear):
             # the hand-written matrix-core kernel (csrc/gemm_mfma.hip): exact fp32 ("f32") or split-bf16 ("bf16x3")
             return _gemm.linear(x, self.weight, self.bias, relu=relu)
         if (f32 and self.bias is not None and self.bias.requires_grad
-                and torch.is_grad_enabled() and n % 4 == 0 and (n // 4) & (n // 4 - 1) == 0 and n <= 1024):
+                and torch.is_grad_enabled() and n % 4 == 0 and (n // 4) & (n // 4 - 1) == 0 and n <= 4096):
             y = _LinearColsum.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias).view(*x.shape[:-1], n)
         else:
             y = F.linear(x, self.weight, self.bias)
