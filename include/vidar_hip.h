@@ -350,9 +350,6 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
                    int64_t strideR, int relu, int precision, int reduce, void* workspace, size_t workspace_bytes,
                    void* stream);
 int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce);
-/* tuning/A-B switch: LDS image sets of the k loop.  1 = one set, two barriers per k-step, 3 workgroups per CU;
- * 2 = two sets, one barrier per k-step, 2 workgroups per CU.  Results do not depend on it.  Returns the previous value. */
-int vidar_gemm_set_stages(int stages);
 size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce);
 
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,

@@ -30,9 +30,6 @@ def lib() -> ctypes.CDLL:
         order = os.environ.get("VIDAR_MSDA_ITEM_ORDER")          # A/B of the MSDA gather kernels' item order (tools, bench)
         if order is not None:
             _lib.vidar_msda_set_item_order(int(order))
-        stages = os.environ.get("VIDAR_GEMM_STAGES")             # A/B of the MFMA GEMM's LDS image sets (1 | 2)
-        if stages is not None:
-            _lib.vidar_gemm_set_stages(int(stages))
     return _lib
 
 

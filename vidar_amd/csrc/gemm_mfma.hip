@@ -286,33 +286,18 @@ __device__ __forceinline__ void fetch(Staged<PREC>& sa, Staged<PREC>& sb, const 
 }
 
 // the k loop of one tile.  On entry the staging registers hold (or are about to receive) the tile's first k-step.
-// STAGES = 1: one LDS image set, two barriers per k-step (write, barrier, [next loads], MFMAs, barrier).
-// STAGES = 2: two image sets, ONE barrier per k-step: [next loads], MFMAs on set s, write the loaded registers into set
-//   s^1 (every wave finished reading it before the previous barrier), barrier -- the conversion / LDS writes of a wave
-//   sit behind its own queued MFMAs instead of in front of a barrier.
-template <int PREC, int ALAY, int BLAY, int STAGES>
+template <int PREC, int ALAY, int BLAY>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, Staged<PREC>& sb, const GemmArgs& g,
-                                         const Tile& T, uint32_t* lds, int tid, uint32_t voa, uint32_t vob) {
+                                         const Tile& T, uint32_t* imgA, uint32_t* imgB, int tid, uint32_t voa, uint32_t vob) {
   constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
   constexpr int IMG_DWORDS = Geo<PREC>::IMG_DWORDS;
-  constexpr int SET = 2 * IMGS * IMG_DWORDS;             // dwords of one image set (A images, then B images)
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
-  int cur = 0;
-  if (STAGES == 2 && T.kbeg < T.kend) {
-    if (ALAY == LAY_K) store_kmajor<PREC>(sa, lds, tid); else store_mnmajor<PREC>(sa, lds, tid);
-    if (BLAY == LAY_K) store_kmajor<PREC>(sb, lds + IMGS * IMG_DWORDS, tid); else store_mnmajor<PREC>(sb, lds + IMGS * IMG_DWORDS, tid);
-    __syncthreads();
-  }
   for (int k0 = T.kbeg; k0 < T.kend; k0 += BK) {
-    uint32_t* imgA = lds + cur * SET;
-    uint32_t* imgB = imgA + IMGS * IMG_DWORDS;
-    if (STAGES == 1) {
-      if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
-      if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
-      __syncthreads();
-    }
+    if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
+    if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
+    __syncthreads();
     if (k0 + BK < T.kend) fetch<PREC, ALAY, BLAY>(sa, sb, g, T, k0 + BK, tid, voa, vob);   // in flight under the MFMAs below
 #pragma unroll
     for (int s = 0; s < Geo<PREC>::NS; ++s) {
@@ -342,15 +327,6 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, 
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u], acc[i][j], 0, 0, 0);
           }
         }
-    }
-    if (STAGES == 2) {
-      if (k0 + BK < T.kend) {
-        uint32_t* nA = lds + (cur ^ 1) * SET;
-        uint32_t* nB = nA + IMGS * IMG_DWORDS;
-        if (ALAY == LAY_K) store_kmajor<PREC>(sa, nA, tid); else store_mnmajor<PREC>(sa, nA, tid);
-        if (BLAY == LAY_K) store_kmajor<PREC>(sb, nB, tid); else store_mnmajor<PREC>(sb, nB, tid);
-      }
-      cur ^= 1;
     }
     __syncthreads();
   }
@@ -421,10 +397,12 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmAr
 // blockIdx + grid, ...  Between the k loop of a tile and its epilogue it decodes the NEXT tile and issues that tile's
 // first global loads, so the store burst of the epilogue (and the launch / address set-up a fresh workgroup would pay)
 // overlaps the latency of the next tile's first operands.
-template <int PREC, int ALAY, int BLAY, int STAGES>
-__global__ __launch_bounds__(THREADS, STAGES == 1 ? 3 : 2) void gemm_mfma_kernel(GemmArgs g) {
+template <int PREC, int ALAY, int BLAY>
+__global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) uint32_t lds[STAGES * 2 * IMGS * Geo<PREC>::IMG_DWORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * IMGS * Geo<PREC>::IMG_DWORDS];
+  uint32_t* imgA = lds;
+  uint32_t* imgB = lds + IMGS * Geo<PREC>::IMG_DWORDS;
   const int tid = threadIdx.x;
   const uint32_t voa = ALAY == LAY_K ? voff_kmajor<PREC>(g.lda, tid) : voff_mnmajor<PREC>(g.lda, tid);
   const uint32_t vob = BLAY == LAY_K ? voff_kmajor<PREC>(g.ldb, tid) : voff_mnmajor<PREC>(g.ldb, tid);
@@ -441,7 +419,7 @@ __global__ __launch_bounds__(THREADS, STAGES == 1 ? 3 : 2) void gemm_mfma_kernel
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    mainloop<PREC, ALAY, BLAY, STAGES>(acc, sa, sb, g, cur, lds, tid, voa, vob);
+    mainloop<PREC, ALAY, BLAY>(acc, sa, sb, g, cur, imgA, imgB, tid, voa, vob);
     const int tn = t + (int)gridDim.x;
     const bool more = tn < g.total;
     if (more) {        // only the tile NUMBER survives the epilogue (registers): the next tile is decoded twice
@@ -490,15 +468,13 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __re
   }
 }
 
-template <int PREC, int STAGES>
+template <int PREC>
 void launch(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStream_t st) {
-  if (a_layout == LAY_K && b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_K, STAGES>), grid, dim3(THREADS), 0, st, g);
-  else if (a_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_MN, STAGES>), grid, dim3(THREADS), 0, st, g);
-  else if (b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_K, STAGES>), grid, dim3(THREADS), 0, st, g);
-  else hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_MN, STAGES>), grid, dim3(THREADS), 0, st, g);
+  if (a_layout == LAY_K && b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_K>), grid, dim3(THREADS), 0, st, g);
+  else if (a_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_MN>), grid, dim3(THREADS), 0, st, g);
+  else if (b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_K>), grid, dim3(THREADS), 0, st, g);
+  else hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_MN>), grid, dim3(THREADS), 0, st, g);
 }
-
-int g_stages = 1;      // LDS image sets of the k loop (vidar_gemm_set_stages): 1 = 3 workgroups per CU, 2 = 2 per CU, one barrier per k-step
 
 int num_cus() {
   static int n = 0;
@@ -525,12 +501,6 @@ int pick_splits(int M, int N, int K, int batch, int bk) {
 }  // namespace
 
 extern "C" {
-
-int vidar_gemm_set_stages(int stages) {
-  const int prev = g_stages;
-  g_stages = stages == 2 ? 2 : 1;
-  return prev;
-}
 
 int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce) {
   if (!reduce) return 1;
@@ -585,15 +555,10 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   // one residency of the chip: 3 workgroups per CU (launch bounds: 3 waves per SIMD), a multiple of 8 so that t & 7
   // stays the workgroup's XCD for every tile it walks.  (Measured against one workgroup per tile and against fetching
   // the next tile after the epilogue: within noise of each other on MI355X, profiles/r04_kbench_gemm_*.)
-  const int resident = num_cus() * (g_stages == 2 ? 2 : 3) / 8 * 8;
+  const int resident = num_cus() * 3 / 8 * 8;
   dim3 grid(k.total > resident ? resident : k.total);
-  if (precision == PREC_BF16X3) {
-    if (g_stages == 2) launch<PREC_BF16X3, 2>(k, a_layout, b_layout, grid, st);
-    else launch<PREC_BF16X3, 1>(k, a_layout, b_layout, grid, st);
-  } else {
-    if (g_stages == 2) launch<PREC_F32, 2>(k, a_layout, b_layout, grid, st);
-    else launch<PREC_F32, 1>(k, a_layout, b_layout, grid, st);
-  }
+  if (precision == PREC_BF16X3) launch<PREC_BF16X3>(k, a_layout, b_layout, grid, st);
+  else launch<PREC_F32>(k, a_layout, b_layout, grid, st);
   if (g.slabs) {
     const int64_t total = (int64_t)M * N;
     int blocks = (int)((total / 4 + 1 + 63) / 64);
