@@ -29,6 +29,7 @@ CASES = [
     ("sca_mid", 2, [(30, 50), (15, 25), (8, 13), (4, 7)], 1000, 8),  # multi-level, several chunks per tile
     ("two_heads", 2, [(12, 20), (6, 10)], 144, 8, 2),  # the golden models' width: embed 64 = 2 heads
     ("hot_tile", 1, [(3, 3)], 5000, 8),                # > 1024 samples per destination tile -> several chunks
+    ("max_samples_per_item", 1, [(10, 12), (5, 6), (3, 3), (2, 2)], 70, 16),   # L*P = 64: 66.5 KB of record LDS (opt-in > 64 KiB)
 ]
 SCATTER = {"atomic": False, "binned": True}
 

@@ -885,6 +885,14 @@ inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
 
 int g_head_major = 1;          // item order of the gather kernels (see ItemMap); vidar_msda_set_item_order
 
+// The gather kernels' records take 1 KiB x (L*P + 1) of dynamic LDS: past 64 KiB (L*P >= 63) a kernel must opt in.
+// Returns false when the device cannot provide it (the caller answers VIDAR_ERR_BAD_ARG instead of a failed launch).
+template <typename K>
+inline bool allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return true;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
 // grid of a gather kernel: banded -- blocks of 32 items, padded to the 8 XCDs; head-major -- blocks of 32 (b, q) pairs x H
 inline void gather_grid(int64_t n_items, int H, int& nblocks, int& grid) {
   if (g_head_major) {
@@ -916,6 +924,7 @@ static int msda_fwd_launch(const float* value, const int64_t* spatial_shapes,
   int nblocks, grid;
   gather_grid(n_items, H, nblocks, grid);
   const size_t lds = rec_lds_bytes(L * P);
+  if (!allow_lds(msda_fwd_kernel, lds)) { (void)hipGetLastError(); return VIDAR_ERR_BAD_ARG; }
   hipLaunchKernelGGL(msda_fwd_kernel, dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, Nv, H, Nq, L,
                      P, n_items, nblocks, g_head_major, pr);
@@ -964,6 +973,7 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     int nblocks, grid;
     gather_grid(n_items, H, nblocks, grid);
     const size_t lds = rec_lds_bytes(L * P);
+    if (!allow_lds(msda_bwd_locw_kernel, lds)) { (void)hipGetLastError(); return VIDAR_ERR_BAD_ARG; }
     hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
                        grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, g_head_major, pr);
