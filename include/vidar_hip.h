@@ -143,8 +143,9 @@ int vidar_knn1_d3_bwd(const float* p1, const float* p2, const int64_t* lengths1,
  *   value [B,Nv,H,C] f32 (C must be 32), spatial_shapes [L,2] i64 (h,w), level_start_index [L] i64,
  *   sampling_loc [B,Nq,H,L,P,2] f32 in [0,1] (x,y), attn_weight [B,Nq,H,L,P] f32, out [B,Nq,H*C].
  * im2col_step of the reference API has no meaning here and is dropped at the Python layer.
- * Limits (VIDAR_ERR_BAD_ARG otherwise): C == 32, L <= 16, L*P <= 64, and `value` smaller than 4 GiB
- * (B*Nv*H*C*4 < 2^32: corner lines are addressed with 32-bit byte offsets from `value`).
+ * Limits (VIDAR_ERR_BAD_ARG otherwise): C == 32, L <= 16, L*P <= 64, and ONE batch element of `value` smaller than
+ * 4 GiB (Nv*H*C*4 < 2^32: corner lines are addressed with 32-bit byte offsets; a larger `value` tensor is processed
+ * in several launches over batch elements, each with its own base pointers -- same results).
  * A sample outside its level, or with a NaN location, contributes nothing (zero output / gradients).
  * bwd: grad_value is zeroed by the call then accumulated with fp32 atomics; grad_sampling_loc and
  * grad_attn_weight are fully written (the reference expects pre-zeroed buffers, function.py:146-148).

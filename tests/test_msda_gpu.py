@@ -281,3 +281,29 @@ def test_rows_with_nan_locations_between_live_rows(scatter):
     assert float(gl[d].abs().max()) == 0.0 and float(gw[d].abs().max()) == 0.0
     assert torch.equal(gl[~d], gl0[~d]) and torch.equal(gw[~d], gw0[~d])
     torch.testing.assert_close(gv, gv0, rtol=1e-4, atol=1e-5 * max(1.0, float(gv0.abs().max())))   # zero grad_out rows add 0
+
+
+@pytest.mark.parametrize("scatter", list(SCATTER))
+def test_value_tensor_past_4_gib_is_split_over_batch_elements(scatter, item_order):
+    """`value` of 4.4 GB (9 x 120 000 pixels x 8 heads x 32 channels): one launch addresses at most 4 GiB with its 32-bit byte
+    offsets, so the entry points split the call over batch elements -- the result must equal the per-element calls"""
+    if item_order == "banded":
+        pytest.skip("one item order is enough for the 4.4 GB case")
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    B, shapes, Nq, P = 9, [(300, 400)], 64, 4
+    g = torch.Generator(device="cuda").manual_seed(3)
+    value = torch.randn(B, 120000, 8, 32, device="cuda", generator=g)
+    assert value.numel() * 4 > (1 << 32)
+    sh = torch.tensor(shapes, dtype=torch.int64, device="cuda")
+    lsi = M.level_start_index(shapes).cuda()
+    loc = torch.rand(B, Nq, 8, 1, P, 2, device="cuda", generator=g)
+    w = torch.softmax(torch.randn(B, Nq, 8, P, device="cuda", generator=g), -1).view(B, Nq, 8, 1, P)
+    go = torch.randn(B, Nq, 256, device="cuda", generator=g)
+    out = F._msda_forward(value, sh, lsi, loc, w)
+    gv, gl, gw = F._msda_backward(value, sh, lsi, loc, w, go, binned=SCATTER[scatter])
+    for b in (0, 4, 8):
+        sl = slice(b, b + 1)
+        assert torch.equal(out[sl], F._msda_forward(value[sl], sh, lsi, loc[sl], w[sl]))
+        gv1, gl1, gw1 = F._msda_backward(value[sl], sh, lsi, loc[sl], w[sl], go[sl], binned=SCATTER[scatter])
+        assert torch.equal(gl[sl], gl1) and torch.equal(gw[sl], gw1)
+        torch.testing.assert_close(gv[sl], gv1, rtol=1e-5, atol=1e-6)      # atomics: summation order

@@ -993,13 +993,33 @@ static bool prep_bad(int bs, int Qn, int R, int mode, int L, int P) {
          (mode == 1 && P % R != 0);
 }
 
+// The kernels address `value` with 32-bit byte offsets, so ONE launch covers at most 4 GiB of it.  A call with a larger
+// `value` tensor (many frames x batch x cameras at once) is split over batch elements: each launch gets its own base
+// pointers, the results are the same.  -> batch elements per launch, 0 when a single element does not fit.
+static int batch_per_launch(int B, int Nv, int H) {
+  const int64_t per = (int64_t)Nv * H * kCh * 4;
+  if (per <= 0) return B > 0 ? B : 1;
+  const int64_t fit = ((1ll << 32) - 1) / per;
+  return (int)(fit < B ? fit : (B > 0 ? B : 1));
+}
+
 int vidar_msda_fwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq,
                        int L, int P, void* stream) {
   VIDAR_ENTER();
-  return msda_fwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, B, Nv, H, C,
-                         Nq, L, P, Prep{}, stream);
+  const int cb = batch_per_launch(B, Nv, H);
+  if (cb <= 0) return VIDAR_ERR_BAD_ARG;
+  const int64_t vs = (int64_t)Nv * H * kCh, is = (int64_t)Nq * H, LP = (int64_t)L * P;
+  int b0 = 0;
+  do {
+    const int nb = B - b0 < cb ? B - b0 : cb;
+    const int rc = msda_fwd_launch(value + b0 * vs, spatial_shapes, level_start_index, sampling_loc + b0 * is * LP * 2,
+                                   attn_weight + b0 * is * LP, out + b0 * is * kCh, nb, Nv, H, C, Nq, L, P, Prep{}, stream);
+    if (rc != 0) return rc;
+    b0 += nb;
+  } while (b0 < B);
+  return 0;
 }
 
 size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P) {
@@ -1014,9 +1034,20 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        float* grad_sampling_loc, float* grad_attn_weight, int B, int Nv, int H, int C,
                        int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
-  return msda_bwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
-                         grad_value, grad_sampling_loc, grad_attn_weight, B, Nv, H, C, Nq, L, P, workspace,
-                         workspace_bytes, Prep{}, stream);
+  const int cb = batch_per_launch(B, Nv, H);
+  if (cb <= 0) return VIDAR_ERR_BAD_ARG;
+  const int64_t vs = (int64_t)Nv * H * kCh, is = (int64_t)Nq * H, LP = (int64_t)L * P;
+  int b0 = 0;
+  do {                                         // (the workspace is reused: the launches of one stream run in order)
+    const int nb = B - b0 < cb ? B - b0 : cb;
+    const int rc = msda_bwd_launch(value + b0 * vs, spatial_shapes, level_start_index, sampling_loc + b0 * is * LP * 2,
+                                   attn_weight + b0 * is * LP, grad_out + b0 * is * kCh, grad_value + b0 * vs,
+                                   grad_sampling_loc + b0 * is * LP * 2, grad_attn_weight + b0 * is * LP, nb, Nv, H, C, Nq,
+                                   L, P, workspace, workspace_bytes, Prep{}, stream);
+    if (rc != 0) return rc;
+    b0 += nb;
+  } while (b0 < B);
+  return 0;
 }
 
 int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
@@ -1027,11 +1058,23 @@ int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
   if (prep_bad(bs, Qn, R, mode, L, P)) return VIDAR_ERR_BAD_ARG;
   if ((int64_t)bs * Qn * Nq * H == 0) return msda_bad(bs * Qn, Nv, H, C, Nq, L, P) ? VIDAR_ERR_BAD_ARG : 0;
   if (!off_raw || !logit_raw || !ref || !loc_out || !w_out) return VIDAR_ERR_BAD_ARG;   // (empty tensors are NULL)
-  Prep pr{};
-  pr.off_raw = off_raw; pr.logit_raw = logit_raw; pr.ref = ref; pr.loc_out = loc_out; pr.w_out = w_out;
-  pr.Qn = Qn; pr.R = R; pr.mode = mode;
-  return msda_fwd_launch(value, spatial_shapes, level_start_index, nullptr, nullptr, out, bs * Qn, Nv, H, C, Nq,
-                         L, P, pr, stream);
+  const int cb = batch_per_launch(bs * Qn, Nv, H) / Qn;            // whole batch items (Qn queue entries each) per launch
+  if (cb <= 0) return VIDAR_ERR_BAD_ARG;
+  const int64_t vs = (int64_t)Nv * H * kCh, is = (int64_t)Nq * H, LP = (int64_t)L * P;
+  int b0 = 0;
+  do {
+    const int nb = bs - b0 < cb ? bs - b0 : cb;
+    const int64_t q0 = (int64_t)b0 * Qn;                             // first (batch, queue) row of this launch
+    Prep pr{};
+    pr.off_raw = off_raw + q0 * is * LP * 2; pr.logit_raw = logit_raw + q0 * is * LP; pr.ref = ref + q0 * Nq * R * 2;
+    pr.loc_out = loc_out + q0 * is * LP * 2; pr.w_out = w_out + q0 * is * LP;
+    pr.Qn = Qn; pr.R = R; pr.mode = mode;
+    const int rc = msda_fwd_launch(value + q0 * vs, spatial_shapes, level_start_index, nullptr, nullptr, out + q0 * is * kCh,
+                                   nb * Qn, Nv, H, C, Nq, L, P, pr, stream);
+    if (rc != 0) return rc;
+    b0 += nb;
+  } while (b0 < bs);
+  return 0;
 }
 
 int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
@@ -1042,11 +1085,25 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
   VIDAR_ENTER();
   if (bs < 0 || Qn <= 0) return VIDAR_ERR_BAD_ARG;
   if ((int64_t)bs * Qn * Nq * H != 0 && (!grad_off_raw || !grad_logit_raw)) return VIDAR_ERR_BAD_ARG;
-  Prep pr{};
-  pr.g_off_raw = grad_off_raw; pr.g_logit_raw = grad_logit_raw; pr.Qn = Qn;
-  return msda_bwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
-                         grad_value, nullptr, nullptr, bs * Qn, Nv, H, C, Nq, L, P, workspace, workspace_bytes,
-                         pr, stream);
+  if (bs == 0) return msda_bwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
+                                      grad_value, nullptr, nullptr, 0, Nv, H, C, Nq, L, P, workspace, workspace_bytes,
+                                      Prep{}, stream);
+  const int cb = batch_per_launch(bs * Qn, Nv, H) / Qn;
+  if (cb <= 0) return VIDAR_ERR_BAD_ARG;
+  const int64_t vs = (int64_t)Nv * H * kCh, is = (int64_t)Nq * H, LP = (int64_t)L * P;
+  int b0 = 0;
+  do {
+    const int nb = bs - b0 < cb ? bs - b0 : cb;
+    const int64_t q0 = (int64_t)b0 * Qn;
+    Prep pr{};
+    pr.g_off_raw = grad_off_raw + q0 * is * LP * 2; pr.g_logit_raw = grad_logit_raw + q0 * is * LP; pr.Qn = Qn;
+    const int rc = msda_bwd_launch(value + q0 * vs, spatial_shapes, level_start_index, sampling_loc + q0 * is * LP * 2,
+                                   attn_weight + q0 * is * LP, grad_out + q0 * is * kCh, grad_value + q0 * vs, nullptr,
+                                   nullptr, nb * Qn, Nv, H, C, Nq, L, P, workspace, workspace_bytes, pr, stream);
+    if (rc != 0) return rc;
+    b0 += nb;
+  } while (b0 < bs);
+  return 0;
 }
 
 }  // extern "C"
