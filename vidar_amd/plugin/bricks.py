@@ -85,7 +85,8 @@ class _LinearColsum(torch.autograd.Function):
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state-dict keys) for the modules on the hot path: on CUDA fp32 tensors the bias
     gradient comes from `vidar_colsum_f32` (one HBM-rate pass) -- torch's generic reduction made ~250 calls / 6 ms of
-    a training step out of these column sums."""
+    a training step out of these column sums.  (The column-sum kernel combines its workgroups' partial sums with fp32
+    atomics: the bias gradient can differ in the last bits from run to run, unlike torch's `sum(0)`.)"""
 
     def forward(self, x, relu=False):
         """relu=True: ReLU(linear(x)) -- in the epilogue of the MFMA GEMM when that path is on"""
