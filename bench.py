@@ -150,6 +150,29 @@ def cpu_baseline(config, threads, with_backbone=True, reduced=True):
                        f"no warm-up): {dt:.1f} s measured on {threads} torch threads, peak RSS {_peak_rss_gb():.0f} GB")
 
 
+def usable_cores():
+    """cores this process may actually run on: the affinity mask, capped by the cgroup CPU quota (a GPU box reports 256
+    logical CPUs while the job's cgroup grants far fewer -- 256 OpenMP threads then run 8 x SLOWER than 16)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def _peak_rss_gb():
     import resource
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
@@ -254,7 +277,7 @@ def cpu_baseline_ops(threads):
     # second column: the rows that scale with cores (OpenMP over rays) on ALL host cores (BASELINE.md section 3 asks
     # for the box's cores; `threads` = 16 is where the torch rows stop scaling -- the MSDA formula on 256 torch threads
     # measured 5 x SLOWER than on 16, profiles/r04_bench_driver_like.json of the first try, so it is not repeated)
-    allc = os.cpu_count() or threads
+    allc = usable_cores()
     if allc > threads:
         by = {r["op"]: r for r in rows}
         O.set_threads(allc)
@@ -308,7 +331,7 @@ def cpu_baseline_record(args, gpu_ops, steps, kernel_rows):
             if r.get("cpu_ms_all_cores"):
                 r["speedup_all_cores"] = round(r["cpu_ms_all_cores"] / r["gpu_ms"], 1)
     out = dict(value=(1e3 / bound_ms) if bound_ms > 0 else None, unit="samples/s", cores=rec["cores"], kind="port",
-               host_cores=os.cpu_count(), all_cores_column=rec.get("all_cores"),
+               host_cores=os.cpu_count(), usable_cores=usable_cores(), all_cores_column=rec.get("all_cores"),
                step_lower_bound_ms=round(bound_ms, 1), ops=rec["ops"],
                sample=(f"op-level, FULL size (BEV 200x200, 6 x 30825 px, 30000 rays): each SURVEY 8(a) op's oracle port "
                        f"timed once on {rec['cores']} threads (knn_cpu: 1), weighted by the GPU step's own launches per "

@@ -45,13 +45,16 @@ def test_pmc_traffic_is_backed_by_committed_profiles():
     import bench
     nbytes, src = bench.pmc_traffic("msda_bwd[L=4,P=8]")
     assert nbytes and nbytes > 8.7e8                        # at least the algorithmic bytes
-    assert "r03_pmc_msda_sca" in src and "calibration" in src
+    # counted on the access pattern the in-model kernel time belongs to: spatially coherent queries (round 4)
+    assert "r04_pmc_msda_sca_coherent" in src and "coherent" in src and "calibration" in src
     for f in ("pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv"):
-        assert (ROOT / "profiles" / "r03_pmc_msda_sca" / f).exists()
+        assert (ROOT / "profiles" / "r04_pmc_msda_sca_coherent" / f).exists()
     assert bench.pmc_traffic("no such kernel") == (None, None)
     # the json is reproducible from the csv files
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "make_pmc_traffic.py"), "profiles/r03_pmc_msda_sca",
-                        "profiles/r03_pmc_FETCH_SIZE_calibration.csv", "profiles/r03_pmc_WRITE_SIZE_calibration.csv"],
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "make_pmc_traffic.py"), "profiles/r04_pmc_msda_sca_coherent",
+                        "profiles/r03_pmc_FETCH_SIZE_calibration.csv", "profiles/r03_pmc_WRITE_SIZE_calibration.csv",
+                        "spatially coherent queries (8 level-0 pixels between neighbours), head-major item order",
+                        "msda_sca_coherent"],
                        capture_output=True, text=True, cwd=ROOT, timeout=60)
     made = json.loads(r.stdout)
     have = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
@@ -59,7 +62,7 @@ def test_pmc_traffic_is_backed_by_committed_profiles():
     cal = have["calibration"]
     assert abs(cal["fetch_factor"] - 2.0) < 0.02 and abs(cal["write_factor"] - 1.0) < 0.01
     bwd = have["msda_bwd[L=4,P=8]"]
-    assert abs(bwd["bytes"] - (bwd["fetch_bytes"] + bwd["write_bytes"])) < 1 and bwd["ratio"] > 1
+    assert abs(bwd["bytes"] - (bwd["fetch_bytes"] + bwd["write_bytes"])) < 1 and 1 < bwd["ratio"] <= 3.0
 
 
 def test_cpu_baseline_leg_reports_a_bounded_sample():
