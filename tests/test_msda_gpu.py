@@ -284,11 +284,9 @@ def test_rows_with_nan_locations_between_live_rows(scatter):
 
 
 @pytest.mark.parametrize("scatter", list(SCATTER))
-def test_value_tensor_past_4_gib_is_split_over_batch_elements(scatter, item_order):
+def test_value_tensor_past_4_gib_is_split_over_batch_elements(scatter):
     """`value` of 4.4 GB (9 x 480 000 pixels x 8 heads x 32 channels): one launch addresses at most 4 GiB with its 32-bit byte
     offsets, so the entry points split the call over batch elements (8 + 1 here) -- the result must equal the per-element calls"""
-    if item_order == "banded":
-        pytest.skip("one item order is enough for the 4.4 GB case")
     from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
     B, shapes, Nq, P = 9, [(600, 800)], 64, 4
     g = torch.Generator(device="cuda").manual_seed(3)
