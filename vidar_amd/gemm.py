@@ -67,6 +67,8 @@ def _f32c(t, what):
         raise RuntimeError(f"vidar_gemm: {what} must be a CUDA tensor (no CPU path)")
     if t.dtype != torch.float32:
         raise TypeError(f"vidar_gemm: {what} must be float32, got {t.dtype}")
+    if t.dim() and t.stride(-1) != 1:
+        raise ValueError(f"vidar_gemm: the last dimension of {what} must be contiguous (strides {tuple(t.stride())})")
     return t
 
 
@@ -107,6 +109,7 @@ def linear_forward(x2, weight, bias=None, relu=False, precision=F32):
 
 def linear_grad_input(g2, weight, precision=F32):
     """g2 [M,N] @ weight [N,K] -> [M,K]"""
+    _f32c(g2, "grad_out"); _f32c(weight, "weight")
     M, N = g2.shape
     K = weight.shape[1]
     gx = torch.empty((M, K), dtype=torch.float32, device=g2.device)
@@ -118,6 +121,7 @@ def linear_grad_input(g2, weight, precision=F32):
 
 def linear_grad_weight(g2, x2, precision=F32):
     """g2 [M,N]^T @ x2 [M,K] -> [N,K]  (the contraction runs over the rows: split over K', slabs summed in order)"""
+    _f32c(g2, "grad_out"); _f32c(x2, "x")
     M, N = g2.shape
     K = x2.shape[1]
     gw = torch.empty((N, K), dtype=torch.float32, device=g2.device)
@@ -183,8 +187,9 @@ def conv_forward(w2, x3, scale=None, shift=None, residual=None, relu=False, prec
                     sR=Co * HW, relu=relu, precision=precision, name="gemm_conv_fwd")
 
 
-def conv_grad_input(w2, g3, precision=F32, row_scale=None):
+def conv_grad_input(w2, g3, precision=F32):
     """w2 [Co,Ci]^T @ g3 [B,Co,HW] -> [B,Ci,HW]"""
+    _f32c(w2, "weight"); _f32c(g3, "grad_out")
     Bn, Co, HW = g3.shape
     Ci = w2.shape[1]
     gx = torch.empty((Bn, Ci, HW), dtype=torch.float32, device=g3.device)
@@ -194,6 +199,7 @@ def conv_grad_input(w2, g3, precision=F32, row_scale=None):
 
 def conv_grad_weight(g3, x3, precision=F32, scale=None):
     """sum_b g3[b] [Co,HW] @ x3[b] [Ci,HW]^T -> [Co,Ci]  (optionally row-scaled by scale[co])"""
+    _f32c(g3, "grad_out"); _f32c(x3, "x")
     Bn, Co, HW = g3.shape
     Ci = x3.shape[1]
     gw = torch.empty((Co, Ci), dtype=torch.float32, device=g3.device)
