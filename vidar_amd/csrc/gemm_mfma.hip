@@ -309,24 +309,31 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, 
           fa[i][p] = frag<PREC, ALAY>(imgA + p * IMG_DWORDS, wm + 32 * i + l31, s, h);
           fb[i][p] = frag<PREC, BLAY>(imgB + p * IMG_DWORDS, wn + 32 * i + l31, s, h);
         }
+      if (PREC == PREC_BF16X3) {
+        // term-major order: the four accumulators of the wave take turns, so the three dependent MFMAs of one
+        // accumulator (lo*hi, hi*lo, hi*hi) are four issues apart instead of back to back
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (PREC == PREC_BF16X3) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[i][0]), al = __builtin_bit_cast(bf16x8, fa[i][IMGS - 1]);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[j][0]), bl = __builtin_bit_cast(bf16x8, fb[j][IMGS - 1]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
-          } else {
-            // (`__builtin_bit_cast(float, vec[u])` on a vector ELEMENT folds every u to element 0 on ROCm 7.2: cast the vector)
-            const f32x4 bf = __builtin_bit_cast(f32x4, fb[j][0]), af = __builtin_bit_cast(f32x4, fa[i][0]);
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int j = 0; j < 2; ++j) {
+              const bf16x8 a = __builtin_bit_cast(bf16x8, fa[i][term == 0 ? IMGS - 1 : 0]);
+              const bf16x8 b = __builtin_bit_cast(bf16x8, fb[j][term == 1 ? IMGS - 1 : 0]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+            }
+      } else {
+        // (`__builtin_bit_cast(float, vec[u])` on a vector ELEMENT folds every u to element 0 on ROCm 7.2: cast the vector)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f32x4 bf = __builtin_bit_cast(f32x4, fb[j][0]), af = __builtin_bit_cast(f32x4, fa[i][0]);
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u], acc[i][j], 0, 0, 0);
-          }
-        }
+            }
+      }
     }
     __syncthreads();
   }
