@@ -561,79 +561,86 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
   }
 }
 
-// one workgroup: counts -> exclusive prefix (left in `counts`, it becomes the fill cursor) and the
-// chunk table: two int4 per chunk, {first record, number of records, level, batch element} and
-// {head, tile row, tile column, 0}, so the accumulate kernel needs no level table of its own
+// counts -> exclusive prefix (`cursor`: the fill pass's per-bin record cursor) and the chunk table: two int4 per chunk,
+// {first record, number of records, level, batch element} and {head, tile row, tile column, 0}, so the accumulate
+// kernel needs no level table of its own.  One workgroup per slab of 8192 bins (rounds 2-3: ONE workgroup walked all
+// slabs, 0.05 ms on a single CU per backward); a workgroup first sums the counts of every earlier slab itself -- a few
+// hundred KB out of L2, redundant but without a second launch or a hand-off between workgroups.
 constexpr int kScanThreads = 1024;
+constexpr int kScanPer = 8;                            // consecutive bins per thread
+constexpr int kScanSlab = kScanThreads * kScanPer;
 __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
-    const int64_t* __restrict__ shapes, int* __restrict__ counts, int4* __restrict__ desc,
-    int* __restrict__ n_chunks, int B, int H, int L) {
+    const int64_t* __restrict__ shapes, const int* __restrict__ counts, int* __restrict__ cursor,
+    int4* __restrict__ desc, int* __restrict__ n_chunks, int B, int H, int L) {
   __shared__ LevelTab t;
   __shared__ int s_wsum[kScanThreads / 64], s_wchk[kScanThreads / 64];
   build_tab(t, shapes, L);
   const int nbins = B * t.T * H;
+  const int base = (int)blockIdx.x * kScanSlab;
+  if (base >= nbins) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int kPer = 8;                              // consecutive bins per thread and slab
-  int carry_s = 0, carry_k = 0;                        // records / chunks before this slab of 8192 bins
-  int c[kPer], cn[kPer];
-#pragma unroll
-  for (int j = 0; j < kPer; ++j) { const int bin = threadIdx.x * kPer + j; c[j] = bin < nbins ? counts[bin] : 0; }
-  for (int base = 0; base < nbins; base += kScanThreads * kPer) {
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {                   // next slab's counts are in flight during this slab's scan
-      const int bin = base + kScanThreads * kPer + threadIdx.x * kPer + j;
-      cn[j] = bin < nbins ? counts[bin] : 0;
-    }
-    int ts = 0, tk = 0;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) { ts += c[j]; tk += (c[j] + kChunk - 1) / kChunk; }
-    int xs = ts, xk = tk;                              // inclusive wave scans of the per-thread totals
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int us = __shfl_up(xs, d, 64), uk = __shfl_up(xk, d, 64);
-      if (lane >= d) { xs += us; xk += uk; }
-    }
-    if (lane == 63) { s_wsum[wave] = xs; s_wchk[wave] = xk; }
-    __syncthreads();
-    int ws = 0, wk = 0, tot_s = 0, tot_k = 0;
-#pragma unroll
-    for (int w = 0; w < kScanThreads / 64; ++w) {
-      const int a = s_wsum[w], q = s_wchk[w];
-      tot_s += a; tot_k += q;
-      if (w < wave) { ws += a; wk += q; }
-    }
-    int s = carry_s + ws + xs - ts, kk = carry_k + wk + xk - tk;
-    // (head, tile, level, batch element) of this thread's first bin by division ONCE, then counted up: the whole scan
-    // runs on one CU, three integer divisions per bin were most of its time
-    int bin = base + threadIdx.x * kPer;
-    int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
-    int l = 0;
-    while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
-    int ty = (tl - t.toff[l]) / t.ntx[l], tx = (tl - t.toff[l]) - ty * t.ntx[l];
-#pragma unroll
-    for (int j = 0; j < kPer; ++j, ++bin) {
-      if (bin < nbins) {
-        counts[bin] = s;
-        for (int i = 0; i < c[j]; i += kChunk) {
-          desc[2 * kk] = make_int4(s + i, min(kChunk, c[j] - i), l, b);
-          desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
-          ++kk;
-        }
-        s += c[j];
-      }
-      if (++h == H) {                                    // next tile
-        h = 0; ++tl;
-        if (++tx == t.ntx[l]) { tx = 0; ++ty; }
-        if (tl == t.T) { tl = 0; ++b; l = 0; tx = ty = 0; }
-        else if (l + 1 < L && tl == t.toff[l + 1]) { ++l; tx = ty = 0; }
-      }
-    }
-    carry_s += tot_s; carry_k += tot_k;
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) c[j] = cn[j];
-    __syncthreads();
+  constexpr int kPer = kScanPer;
+  // records / chunks before this slab
+  int ps = 0, pk = 0;
+  for (int i = threadIdx.x; i < base; i += kScanThreads) {
+    const int c0 = counts[i];
+    ps += c0; pk += (c0 + kChunk - 1) / kChunk;
   }
-  if (threadIdx.x == 0) *n_chunks = carry_k;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { ps += __shfl_xor(ps, d, 64); pk += __shfl_xor(pk, d, 64); }
+  if (lane == 0) { s_wsum[wave] = ps; s_wchk[wave] = pk; }
+  __syncthreads();
+  int carry_s = 0, carry_k = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) { carry_s += s_wsum[w]; carry_k += s_wchk[w]; }
+  __syncthreads();
+  int c[kPer];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) { const int bin = base + threadIdx.x * kPer + j; c[j] = bin < nbins ? counts[bin] : 0; }
+  int ts = 0, tk = 0;
+#pragma unroll
+  for (int j = 0; j < kPer; ++j) { ts += c[j]; tk += (c[j] + kChunk - 1) / kChunk; }
+  int xs = ts, xk = tk;                                // inclusive wave scans of the per-thread totals
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int us = __shfl_up(xs, d, 64), uk = __shfl_up(xk, d, 64);
+    if (lane >= d) { xs += us; xk += uk; }
+  }
+  if (lane == 63) { s_wsum[wave] = xs; s_wchk[wave] = xk; }
+  __syncthreads();
+  int ws = 0, wk = 0, tot_k = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) {
+    const int a = s_wsum[w], q = s_wchk[w];
+    tot_k += q;
+    if (w < wave) { ws += a; wk += q; }
+  }
+  int s = carry_s + ws + xs - ts, kk = carry_k + wk + xk - tk;
+  // (head, tile, level, batch element) of this thread's first bin by division ONCE, then counted up
+  int bin = base + threadIdx.x * kPer;
+  int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
+  int l = 0;
+  while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
+  int ty = (tl - t.toff[l]) / t.ntx[l], tx = (tl - t.toff[l]) - ty * t.ntx[l];
+#pragma unroll
+  for (int j = 0; j < kPer; ++j, ++bin) {
+    if (bin < nbins) {
+      cursor[bin] = s;
+      for (int i = 0; i < c[j]; i += kChunk) {
+        desc[2 * kk] = make_int4(s + i, min(kChunk, c[j] - i), l, b);
+        desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
+        ++kk;
+      }
+      s += c[j];
+    }
+    if (++h == H) {                                      // next tile
+      h = 0; ++tl;
+      if (++tx == t.ntx[l]) { tx = 0; ++ty; }
+      if (tl == t.T) { tl = 0; ++b; l = 0; tx = ty = 0; }
+      else if (l + 1 < L && tl == t.toff[l + 1]) { ++l; tx = ty = 0; }
+    }
+  }
+  if (threadIdx.x == 0 && base + kScanSlab >= nbins) *n_chunks = carry_k + tot_k;        // the last slab
 }
 
 // Accumulate kernel.  One chunk (<= kChunk records of one destination tile) per wave: the wave accumulates the tile's
@@ -852,12 +859,12 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
   }
 }
 
-// workspace layout of the binned backward (all int32): [counts/cursor: nbins_bound][n_chunks: 4]
+// workspace layout of the binned backward (all int32): [counts: nbins_bound][cursor: nbins_bound][n_chunks: 4]
 // [chunk table: 4 * max_chunks][records: n_samples].  The level shapes live on the device, so the host
 // sizes the tables from a bound (bin_plan).
 struct BinPlan {
   int64_t n_samples, nbins_bound, max_chunks, tiles_bound;
-  size_t off_chunks, off_desc, off_rec, bytes;
+  size_t off_cursor, off_chunks, off_desc, off_rec, bytes;
   bool ok;
 };
 inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
@@ -867,7 +874,8 @@ inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
   p.tiles_bound = ((int64_t)Nv * (1 + kTile)) / (kTile * kTile) + 2 * L + 1;
   p.nbins_bound = (int64_t)B * H * p.tiles_bound;
   p.max_chunks = p.n_samples / kChunk + p.nbins_bound;
-  p.off_chunks = (sizeof(int) * (size_t)p.nbins_bound + 15) & ~(size_t)15;      // 16-byte aligned tables behind it
+  p.off_cursor = (sizeof(int) * (size_t)p.nbins_bound + 15) & ~(size_t)15;      // [counts][cursor]: 16-byte aligned tables
+  p.off_chunks = 2 * p.off_cursor;
   p.off_desc = p.off_chunks + 16;
   p.off_rec = p.off_desc + 32 * (size_t)p.max_chunks;
   p.bytes = p.off_rec + sizeof(int) * (size_t)p.n_samples;
@@ -953,6 +961,7 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     if (!p.ok || workspace_bytes < p.bytes) return VIDAR_ERR_BAD_ARG;
     char* ws = (char*)workspace;
     int* counts = (int*)ws;
+    int* cursor = (int*)(ws + p.off_cursor);
     int* n_chunks = (int*)(ws + p.off_chunks);
     int4* desc = (int4*)(ws + p.off_desc);
     int* rec = (int*)(ws + p.off_rec);
@@ -962,10 +971,11 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     const size_t blds = sizeof(int) * (size_t)p.tiles_bound;
     hipLaunchKernelGGL(msda_bin_kernel<false>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
                        counts, rec, H, Nq, L, P);
-    hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, spatial_shapes, counts, desc,
+    const int nslabs = (int)((p.nbins_bound + kScanSlab - 1) / kScanSlab);
+    hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(nslabs), dim3(kScanThreads), 0, s, spatial_shapes, counts, cursor, desc,
                        n_chunks, B, H, L);
     hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
-                       counts, rec, H, Nq, L, P);
+                       cursor, rec, H, Nq, L, P);
     const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
