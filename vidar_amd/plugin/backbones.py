@@ -83,12 +83,9 @@ class _ModulatedDeformConv(Function):
             go = _affine_act_backward(go, y if relu else go, scale, relu, False)[0]
         if gemm_mode == "lib":
             grad_weight = torch.bmm(go, cols.transpose(1, 2)).sum(0).reshape(weight.shape)
-            if G.mode() == "auto" and Cout <= 256:
-                # [C*kh*kw, Cout] x [Cout, Ho*Wo] with a short contraction: the fp32 MFMA kernel runs it at 0.39 ms where the
-                # library's best solution takes 0.49 (stage 3, profiles/r04_kbench_gemm.log); same fp32 arithmetic
-                grad_cols = G.conv_grad_input(weight.reshape(Cout, -1), go, G.F32)
-            else:
-                grad_cols = torch.bmm(weight.reshape(1, Cout, -1).transpose(1, 2).expand(N, -1, -1), go)
+            # (the fp32 MFMA kernel for this product measured 0.39 vs 0.49 ms against the library's DEFAULT solution in
+            #  kbench, but SLOWER than the TunableOp-selected one inside the step: 353.0 vs 349.1 ms; not used)
+            grad_cols = torch.bmm(weight.reshape(1, Cout, -1).transpose(1, 2).expand(N, -1, -1), go)
         else:
             prec = G.precision_of(gemm_mode)
             grad_weight = G.conv_grad_weight(go, cols, prec).reshape(weight.shape) if ctx.needs_input_grad[3] else None
