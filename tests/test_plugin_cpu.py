@@ -171,3 +171,32 @@ def test_custom_ms_deformable_attention_is_registered_and_sequence_first():
                   spatial_shapes=shapes, level_start_index=lsi)
     assert out_a.shape == (7, 2, 64)
     torch.testing.assert_close(out_a, out_b.permute(1, 0, 2), rtol=1e-5, atol=1e-6)
+
+
+def test_memory_efficient_3future_variant_matches_the_released_config():
+    """nusc_1_8_subset/mem_efficient_vidar_1_8_nusc_3future.py: only the last future frame is supervised, the head predicts
+    the current frame only (per_frame_loss_weight (1.0,)), LatentRendering step 1.0 -- and the step runs end to end"""
+    from oracle import cpu_ops
+    from vidar_amd import train as T
+    cfg = get_config("mem_efficient_vidar_1_8_nusc_3future", bev_h=24, bev_w=24)
+    m = cfg["model"]
+    assert m["supervise_all_future"] is False and m["future_pred_frame_num"] == 3
+    head = m["future_pred_head"]
+    assert head["pred_history_frame_num"] == 0 and head["pred_future_frame_num"] == 0
+    assert tuple(head["per_frame_loss_weight"]) == (1.0,)
+    ref = Path("/root/reference/projects/configs/vidar_pretrain/nusc_1_8_subset/mem_efficient_vidar_1_8_nusc_3future.py")
+    if ref.exists():
+        from vidar_amd.plugin.config import Config
+        rc = Config.fromfile(str(ref))
+        assert rc.model.supervise_all_future is False and rc.model.future_pred_frame_num == m["future_pred_frame_num"]
+        assert rc.model.future_pred_head.pred_history_frame_num == 0
+        assert tuple(rc.model.future_pred_head.per_frame_loss_weight) == (1.0,)
+    torch.manual_seed(0); np.random.seed(0)
+    _, batch = _small_batch("vidar_1_8_nusc_3future")            # same data recipe (4 future frames)
+    model = T.build_model(cfg).train()
+    with cpu_ops.patched():
+        losses = model(return_loss=True, **batch)
+    assert losses and all(torch.isfinite(v) for v in losses.values())
+    full = T.build_model(get_config("vidar_1_8_nusc_3future", bev_h=24, bev_w=24)).train()
+    with cpu_ops.patched():
+        assert len(full(return_loss=True, **batch)) > len(losses)       # fewer supervised frames than the full recipe
