@@ -382,7 +382,9 @@ def kernel_rooflines(dev):
         N, M = tindex.shape
         vol = sigma.numel() * 4
         out = dvxlr.render(sigma, origin, points, tindex)
-        cnt = int(((out[3] != 0).any(-1)).sum())             # traversed voxels (dvr bytes depend on it)
+        live = (out[3] != 0).any(-1)                          # [N, M, 1026]: the samples of every ray
+        cnt = int(live.sum())                                 # traversed voxels (dvr bytes depend on it)
+        longest = int(live.sum(-1).max())                     # samples of the longest ray
         add(f"dvxlr.render[M={M}]", hip_time(lambda: dvxlr.render(sigma, origin, points, tindex)),
             vol + N * M * 16 + N * M * 4 * (2 + 1026 * 4), note="16.4 KB/ray of API-mandated padded rows")
         em = out[2] * 0.5
@@ -393,9 +395,17 @@ def kernel_rooflines(dev):
         add(f"dvr.render_forward[M={M}]",
             hip_time(lambda: dvr.render_forward(sigma, origin, points, tindex, [T_, 16, 200, 200], "train")),
             vol + N * M * 24 + cnt * 4, bound="fp64 issue (sequential DDA per lane), not HBM")
+        # the bound as a NUMBER: a ray is a serial chain of fp64 traversal steps, a wave lasts as long as its longest ray, and
+        # with <= 1 wave per SIMD (469 waves at 30 000 rays) the launch lasts as long as its longest wave
+        rows[-1]["serial_chain"] = dict(longest_ray_steps=longest, total_steps=cnt,
+                                        us_per_step_of_longest_ray=round(rows[-1]["avg_ms"] * 1e3 / max(longest, 1), 3),
+                                        waves=(N * M + 63) // 64, simds=1024)
         add(f"dvr.render[M={M}]", hip_time(lambda: dvr.render(sigma, origin, points, tindex, "l1")),
             2 * vol + N * M * 24 + cnt * 12, bound="fp64 issue + per-lane atomics, not HBM")
-        del out, em
+        rows[-1]["serial_chain"] = dict(longest_ray_steps=longest, total_steps=cnt,
+                                        us_per_step_of_longest_ray=round(rows[-1]["avg_ms"] * 1e3 / max(longest, 1), 3),
+                                        waves=(N * M + 63) // 64, simds=1024)
+        del out, em, live
     from vidar_amd.third_lib.chamferdist import knn_points
     rng = np.random.default_rng(0)
     a3, b3 = (torch.from_numpy(rng.uniform(-50, 50, (1, 30000, 3)).astype(np.float32)).to(dev) for _ in range(2))
