@@ -23,12 +23,19 @@
 // k-step in fp32 mode, 16 in bf16 mode):
 //   K-major  operand: [128 rows][U units + 4 pad]    row stride 144 / 80 B: ds_read_b128 fragments are conflict free
 //                     (slot stride 9 / 5 is odd, and each of the instruction's four 16-lane groups covers all 16
-//                     residues of the row index)
+//                     residues of the row index); the 8-byte staging stores of bf16 mode are 2-way conflicted
+//                     (SQ_LDS_BANK_CONFLICT = a third of the LDS cycles, with LDS active 26 % of the time)
 //   MN-major operand: [U units][128 rows + 8 pad]    four ds_read_b32 per fragment, 32 consecutive dwords per group
 // A lane's fragment is always the four units 8*s + 4*(lane>>5) + {0..3} of its row -- in bf16 mode they ARE the
 // eight consecutive k of one 32x32x16 operand, in fp32 mode they feed four 32x32x2 MFMAs whose two k slots
 // (lane halves) take units t and 4 + t; both operands use the same assignment, which is all a contraction needs.
 // An accumulator register of a wave is two rows of 32 consecutive n: the epilogue's stores are whole 128-byte lines.
+//
+// Memory side: every global access is a buffer instruction whose descriptor starts at the workgroup's tile -- one 32-bit
+// per-thread offset, the k / row advance in a scalar register, and the descriptor's END doing the bounds checking
+// (rows past the matrix read 0 / are not stored); the lanes of a load run along the contiguous index so that a wave
+// instruction moves whole 128-byte lines.  Workgroups are persistent (one chip residency) and request the next tile's
+// first operands before they store the current tile.  profiles/r04_kbench_gemm*.log, r04_pmc_gemm/: DESIGN.md section 4a.
 //
 // Epilogue: y = relu?( acc * scale[m|n] + shift[m|n] + residual[m,n] ) -- the bias of F.linear, the frozen
 // BatchNorm + residual + ReLU that follows every 1x1 convolution of the ResNet bottlenecks
@@ -71,7 +78,7 @@ struct GemmArgs {
   const float* A; const float* B; float* C;
   int64_t lda, ldb, ldc, sA, sB, sC;
   int M, N, K;
-  int splits, k_chunk;          // blockIdx.z = batch * splits + split ; the split covers k in [split*k_chunk, +k_chunk)
+  int splits, k_chunk;          // z = batch * splits + split ; the split covers k in [split*k_chunk, +k_chunk)
   int slabs;                    // 1: every z writes the slab ws[z] (no epilogue); 0: z = batch item, epilogue to C
   const float* scale; const float* shift; int vec_axis;      // 0: indexed by n, 1: indexed by m
   const float* residual; int64_t ldr, sR;
