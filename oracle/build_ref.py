@@ -13,6 +13,12 @@ gpurun-ignored).  Reference sources are read where they lie and are never copied
     `vidar_ref_launch(kernel<scalar_t>, blocks, threads, ` on its way into g++'s stdin.  The kernel
     bodies (all arithmetic) are compiled exactly as written, one host call per CUDA thread.
     -> oracle/_ref/ref_dvr*.so, ref_dvxlr*.so, ref_dvxlr_v2*.so
+  * projects/mmdet3d_plugin/bevformer/backbones/ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh -- the
+    reference's in-tree copy of the deformable-attention bilinear sampling and its gradients
+    (`dcnv3_im2col_bilinear`, `dcnv3_col2im_bilinear_gm` and the two kernels around them): the same
+    shim; the filter drops the two CUDA-only includes, the __shared__-memory backward variants and
+    the `<<<>>>` host launchers, and oracle/ref_dcnv3_bind.cpp is appended to the same translation unit
+    -> oracle/_ref/ref_dcnv3.so   (pins oracle/msda.py, tests/test_oracle_msda.py)
 
 gcc on x86-64 without -mfma cannot fuse multiply-adds, so these builds evaluate the reference's
 expressions in strict IEEE order; -ffp-contract=off is passed anyway.
@@ -36,6 +42,18 @@ CU_MODULES = {
     "ref_dvxlr": ("third_lib/dvxlr/dvxlr.cu", "REF_DVXLR"),
     "ref_dvxlr_v2": ("third_lib/dvxlr/dvxlr_v2.cu", "REF_DVXLR_V2"),
 }
+
+
+DCNV3_CUH = "projects/mmdet3d_plugin/bevformer/backbones/ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh"
+
+
+def _dcnv3_host_text(text: str) -> str:
+    """Keep the device functions, `dcnv3_im2col_gpu_kernel` and `dcnv3_col2im_gpu_kernel_gm`."""
+    text = re.sub(r"#include <(ATen/cuda/CUDAContext\.h|THC/THCAtomics\.cuh)>\n", "", text)
+    shm = text.index("template <typename scalar_t, unsigned int blockSize>")
+    gm = text.index("template <typename scalar_t>\n__global__ void dcnv3_col2im_gpu_kernel_gm(")
+    host = text.index("template <typename scalar_t>\nvoid dcnv3_im2col_cuda(")
+    return text[:shm] + text[gm:host]
 
 
 def _torch_flags():
@@ -91,6 +109,19 @@ def build(verbose: bool = True) -> list[Path]:
             obj_k.unlink()
             obj_b.unlink()
         built.append(out)
+
+    # --- ops_dcnv3 bilinear sampling kernels (the in-tree MSDA arithmetic) -------------------------
+    src = REF / DCNV3_CUH
+    out = so_path("ref_dcnv3")
+    bind = HERE / "ref_dcnv3_bind.cpp"
+    if _needs(out, [src, bind, *me]):
+        if verbose:
+            print(f"[build_ref] {DCNV3_CUH} -> {out.name}", flush=True)
+        text = _dcnv3_host_text(src.read_text()) + "\n" + bind.read_text()
+        subprocess.run(["g++", *cxx, *inc, f"-I{HERE / 'ref_shim'}", "-include",
+                        str(HERE / "ref_shim" / "ref_prelude.h"), "-DTORCH_EXTENSION_NAME=ref_dcnv3",
+                        "-x", "c++", "-shared", "-", *ld, "-o", str(out)], input=text.encode(), check=True)
+    built.append(out)
 
     # --- chamferdist CPU KNN, unmodified ----------------------------------------------------------
     cd = REF / "third_lib/chamfer_dist/chamferdist/chamferdist"

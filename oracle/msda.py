@@ -1,15 +1,23 @@
 """CPU oracle for multi-scale deformable attention -- TEST INFRASTRUCTURE.
 
-PARITY UNPINNED: the reference reaches this op through mmcv-full==1.4.0 (README.md:103), which is
-neither vendored under /root/reference nor installable here.  This restates the published
-semantics of mmcv's `ms_deform_attn` (identical to `multi_scale_deformable_attn_pytorch`, the CPU
-branch the reference itself calls at spatial_cross_attention.py:392-394,
-temporal_self_attention.py:249-252, vidar_decoder.py:507-509):
+The reference reaches this op through mmcv-full==1.4.0 (README.md:103), which is neither vendored
+under /root/reference nor installable here; its call sites are spatial_cross_attention.py:392-394,
+temporal_self_attention.py:249-252, vidar_decoder.py:507-509:
     out[b,q,h*C+c] = sum_{l,p} w[b,q,h,l,p] * bilinear(value_l[b,:,h,c], loc[b,q,h,l,p])
     pixel = loc * (W_l, H_l) - 0.5, zero padding outside  (grid_sample, align_corners=False).
-Two independent formulations are provided and cross-checked in tests/test_oracle_msda.py:
-`msda_gather` (explicit 4-corner gather, any float dtype, differentiable by autograd) and
-`msda_grid_sample` (per-level F.grid_sample)."""
+PINNED (round 5) against the copy of this arithmetic the reference DOES hold in-tree, DCNv3
+(projects/mmdet3d_plugin/bevformer/backbones/ops_dcnv3): one MSDA level = `dcnv3_core_pytorch`
+(functions/dcnv3_func.py:147-190) with group = heads, kh*kw = points, mask = weights, and the CUDA
+kernels `dcnv3_im2col_gpu_kernel` / `dcnv3_col2im_gpu_kernel_gm` with their bilinear device functions
+(src/cuda/dcnv3_im2col_cuda.cuh:33-276, :776-839) -- Deformable-DETR's kernel under another name,
+with the same `loc > -1 && loc < size` admission test and the same grad_loc / grad_w formulas.
+tests/test_oracle_msda.py checks both formulations below against golden vectors made by the first
+(tests/golden/make_msda_golden.py, forward + the three gradients) and against the second compiled
+for the host (oracle/build_ref.py -> oracle/_ref/ref_dcnv3.so).
+Two formulations: `msda_gather` (explicit 4-corner gather with the CUDA kernels' admission test, any
+float dtype, differentiable by autograd) and `msda_grid_sample` (per-level F.grid_sample, the form of
+the reference's CPU branch).  They differ only on the measure-zero set pixel == -1 exactly, where
+grid_sample's autograd still returns a location gradient and the CUDA kernels return none."""
 from __future__ import annotations
 
 import torch
@@ -31,6 +39,7 @@ def msda_gather(value, shapes, loc, w):
         y = loc[:, :, :, l, :, 1] * Hl - 0.5
         x0 = torch.floor(x); y0 = torch.floor(y)
         lx = x - x0; ly = y - y0
+        inside = (x > -1) & (y > -1) & (x < Wl) & (y < Hl)       # dcnv3_im2col_cuda.cuh:262-263
         acc = 0
         for dy, wy in ((0, 1 - ly), (1, ly)):
             for dx, wx in ((0, 1 - lx), (1, lx)):
@@ -38,7 +47,7 @@ def msda_gather(value, shapes, loc, w):
                 ok = (xi >= 0) & (xi < Wl) & (yi >= 0) & (yi < Hl)
                 idx = (yi.clamp(0, Hl - 1) * Wl + xi.clamp(0, Wl - 1))
                 g = v[bi, idx, hi]                                # [B,Nq,H,P,C]
-                acc = acc + g * (wy * wx * ok).unsqueeze(-1)
+                acc = acc + g * (wy * wx * (ok & inside)).unsqueeze(-1)
         out = out + (acc * w[:, :, :, l].unsqueeze(-1)).sum(3)
     return out.reshape(B, Nq, H * C)
 

@@ -1,6 +1,7 @@
-"""GPU parity: HIP MSDA forward/backward vs the CPU oracle (fp64 gather formulation).
-Tolerance: fp32 accumulation of <=32 products per output -> rtol 1e-4 / atol 1e-5 (stated here as
-the op-level tolerance; the oracle itself is 'parity unpinned', see oracle/msda.py)."""
+"""GPU parity: HIP MSDA forward/backward vs the CPU oracle (fp64 gather formulation) and vs golden vectors
+made by the reference's own in-tree copy of this arithmetic (`dcnv3_core_pytorch`, tests/golden/make_msda_golden.py).
+Tolerance: fp32 accumulation of <=32 products per output -> rtol 1e-4 / atol 1e-5 (the op-level tolerance;
+the oracle is pinned against the reference's DCNv3 code, oracle/msda.py, tests/test_oracle_msda.py)."""
 import pytest
 import torch
 
@@ -64,6 +65,32 @@ def test_msda_fwd_bwd(case, scatter):
     for g, r, nm in zip(got, gref, ["grad_value", "grad_loc", "grad_w"]):
         scale = max(1.0, float(r.abs().max()))
         torch.testing.assert_close(g.cpu().double(), r, rtol=2e-4, atol=2e-5 * scale, msg=lambda m: nm + m)
+
+
+@pytest.mark.parametrize("scatter", list(SCATTER))
+@pytest.mark.parametrize("name", ["tsa_L1_P4", "sca_L4_P8"])
+def test_msda_matches_reference_dcnv3_golden(name, scatter):
+    """HIP forward + the three gradients against vectors the REFERENCE produced (fp64 `dcnv3_core_pytorch` per level,
+    summed over levels, autograd gradients) on fp32-representable value / weights / grad_out; the fp64 locations are
+    rounded to fp32 for the device, hence the location-rounding term in the tolerances (|d out / d pixel| ~ 3)."""
+    import numpy as np
+    from pathlib import Path
+    from vidar_amd.plugin.modules import multi_scale_deformable_attn_function as F
+    d = np.load(Path(__file__).parent / "golden" / f"msda_{name}.npz")
+    shapes = [(int(a), int(b)) for a, b in d["shapes"]]
+    sh = torch.from_numpy(d["shapes"]).cuda()
+    lsi = M.level_start_index(shapes).cuda()
+    value = torch.from_numpy(d["value"]).cuda()
+    loc = torch.from_numpy(d["loc"]).float().cuda()
+    w = torch.from_numpy(d["w"]).cuda()
+    gout = torch.from_numpy(d["gout"]).cuda()
+    out = F.MultiScaleDeformableAttnFunction_fp32.apply(value, sh, lsi, loc, w, 64)
+    torch.testing.assert_close(out.cpu().double(), torch.from_numpy(d["out"]), rtol=1e-4, atol=5e-5)
+    got = F._msda_backward(value, sh, lsi, loc, w, gout, binned=SCATTER[scatter])
+    for g, nm in zip(got, ["grad_value", "grad_loc", "grad_w"]):
+        r = torch.from_numpy(d[nm])
+        scale = max(1.0, float(r.abs().max()))
+        torch.testing.assert_close(g.cpu().double(), r, rtol=2e-4, atol=5e-5 * scale, msg=lambda m: nm + m)
 
 
 def test_empty_queries():
