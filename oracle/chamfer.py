@@ -8,7 +8,9 @@ tests/test_oracle_chamfer.py.
 
 chamfer_distance_mmdet3d restates mmdet3d v0.17.1 `mmdet3d.models.losses.chamfer_distance`
 (call site dense_heads/vidar_head_base.py:654).  mmdet3d is NOT vendored in /root/reference and
-not installable here: PARITY UNPINNED for that function (documented formula only).
+not installable here: its nearest-neighbour part (per-point min d^2 and arg-min, both directions) is
+checked against the reference's own knn_cpu.cpp build (tests/test_oracle_chamfer.py::
+test_training_chamfer_formula_rests_on_the_reference_knn); the `.mean(1).mean()` normalisation stays recalled.
 compute_chamfer_distance{,_inner}: bevformer/utils/e2e_predictor_utils.py:163-183.
 """
 from __future__ import annotations

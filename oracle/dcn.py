@@ -1,9 +1,14 @@
 """CPU oracle for modulated deformable convolution v2 -- TEST INFRASTRUCTURE.
 
-PARITY UNPINNED: mmcv-full 1.4.0 (`mmcv.ops.modulated_deform_conv2d`) is third party and neither
-vendored in /root/reference nor installable here; this restates its published semantics with
-F.grid_sample (align_corners=True maps pixel centres exactly; zero padding == the op's per-corner
-bounds checks).  offset [N,2K,Ho,Wo] holds (dy,dx) per tap, mask [N,K,Ho,Wo]."""
+mmcv-full 1.4.0 (`mmcv.ops.modulated_deform_conv2d`) is third party and neither vendored in
+/root/reference nor installable here; this restates its published semantics with F.grid_sample
+(align_corners=True maps pixel centres exactly; zero padding == the op's per-corner bounds checks).
+offset [N,2K,Ho,Wo] holds (dy,dx) per tap, mask [N,K,Ho,Wo].
+PINNED (round 5) as far as reference-held code reaches: the SAMPLER (bilinear taps, zero padding, base
+position, stride / padding / dilation, modulation, and all three gradients) equals the reference's
+in-tree deformable kernels `dcnv3_im2col_gpu_kernel` / `dcnv3_col2im_gpu_kernel_gm`
+(ops_dcnv3/src/cuda/dcnv3_im2col_cuda.cuh) compiled for the host -- tests/test_oracle_dcn.py.  What
+stays recalled from mmcv is the channel order of `offset` only."""
 from __future__ import annotations
 
 import torch

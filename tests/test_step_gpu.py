@@ -65,10 +65,20 @@ def test_hip_step_matches_cpu_oracle_step(name, bs, bev):
     out = model(return_loss=True, **_to(batch, "cuda"))
     for k in ref:
         np.testing.assert_allclose(float(out[k]), float(ref[k]), rtol=2e-3, atol=1e-5, err_msg=k)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
     grads = torch.autograd.grad(sum(out.values()), [p for p in model.parameters() if p.requires_grad])
     num = sum(float(((a.cpu() - b) ** 2).sum()) for a, b in zip(grads, ref_grads))
     den = sum(float((b ** 2).sum()) for b in ref_grads)
     assert (num / den) ** 0.5 < 5e-3, f"relative gradient error {(num / den) ** 0.5:.2e}"
+    # ... and per parameter tensor, so that a wrong gradient on a small tensor (a bias, level_embeds, lora_a)
+    # cannot hide in the aggregate: relative L2 error <= 2e-2 per tensor, with a floor of 1e-4 of the whole
+    # gradient's norm for tensors whose own gradient is at rounding level
+    bad = []
+    for n, a, b in zip(names, grads, ref_grads):
+        err = float((a.cpu() - b).norm())
+        if err > 2e-2 * float(b.norm()) + 1e-4 * den ** 0.5:
+            bad.append(f"{n}: |err| {err:.3e} vs |grad| {float(b.norm()):.3e}")
+    assert not bad, "per-parameter gradient mismatch:\n" + "\n".join(bad)
 
 
 def test_forward_test_reports_chamfer_per_frame():
