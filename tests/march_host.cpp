@@ -8,8 +8,21 @@
 #include <vector>
 
 #include "dvr_march.h"
+#include "dvr_par.h"
 
 using namespace vidar_march;
+
+// -DVIDAR_MARCH_PAR: every traversal below runs in its step-parallel form (dvr_par.h: per-axis chains, merge by
+// rank, rounded-path chains) instead of the sequential loop; the integrator and everything after it are shared.
+#ifdef VIDAR_MARCH_PAR
+struct HostTraversal {
+  template <int MODE, class Sink>
+  double run(const RayIn& r, const Vol& g, Sink& sink) const { return march_par<MODE>(r, g, sink); }
+};
+#else
+using HostTraversal = SequentialTraversal;
+#endif
+static int g_par_regular = 0, g_par_total = 0;
 
 extern "C" {
 
@@ -25,7 +38,7 @@ int host_dvr_render_forward(const float* sigma, const float* origin, const float
       if (r.valid) {
         NoEmit ne;
         Integrator<kRounded, kDvrMaxD, NoEmit> a(sigma + ((size_t)n * T + r.ts) * vol, Y, X, ne);
-        const double len = march<kRounded>(r, g, a);
+        const double len = HostTraversal().run<kRounded>(r, g, a);
         if (a.k > 0) {
           pred = (float)(a.d0 + a.S);
           gt = (float)(train_phase ? fmin(len, a.dprev) : len);
@@ -59,7 +72,7 @@ int host_dvr_render(const float* sigma, const float* origin, const float* points
         const size_t slice = ((size_t)n * T + r.ts) * vol;
         NoEmit ne;
         Integrator<kClassic, kDvrMaxD, NoEmit> a(sigma + slice, Y, X, ne);
-        const double len = march<kClassic>(r, g, a);
+        const double len = HostTraversal().run<kClassic>(r, g, a);
         if (a.k > 0) {
           const double exp_d = a.d0 + a.S, gt_d = fmin(len, a.dprev);
           pred = (float)exp_d; gt = (float)gt_d;
@@ -69,7 +82,7 @@ int host_dvr_render(const float* sigma, const float* origin, const float* points
           else if (loss_type == 2) dl = (exp_d >= gt_d) ? (1.0 / gt_d) : -(1.0 / gt_d);
           HostGrad hg{grad_sigma + slice, a.S, dl};
           Integrator<kClassic, kDvrMaxD, HostGrad> b(sigma + slice, Y, X, hg);
-          march<kClassic>(r, g, b);
+          HostTraversal().run<kClassic>(r, g, b);
         }
       }
       pred_dist[(size_t)n * M + c] = pred;
@@ -91,7 +104,9 @@ int host_dvxlr_render(const float* sigma, const float* sigma_regul, const float*
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < M; ++c) {
       est_steps[(size_t)n * M + c] = estimate_steps(load_ray(origin, points, tindex, n, c, M, g), g);
-      dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g);
+      dvxlr_march_ray(sigma, origin, points, tindex, pred_dist, gt_dist, indices, n, c, M, g, HostTraversal());
+      const RayIn rr = load_ray(origin, points, tindex, n, c, M, g);
+      if (rr.valid) { ++g_par_total; g_par_regular += par_setup<kRoundedMerged>(rr, g).regular ? 1 : 0; }
     }
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < M; ++c) {
@@ -130,5 +145,8 @@ int host_dvxlr_render(const float* sigma, const float* sigma_regul, const float*
     }
   return 0;
 }
+
+// how many of the valid rays seen by host_dvxlr_render so far were of the regular (step-parallel) class
+int host_par_regular_count(int* total) { *total = g_par_total; return g_par_regular; }
 
 }  // extern "C"

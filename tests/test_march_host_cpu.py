@@ -19,7 +19,9 @@ L = 1026
 
 # the header as shipped: a sample's density is consumed one commit later (same arithmetic in the same order, see
 # dvr_march.h; on the GPU the load gets a whole traversal step to arrive: dvxlr.render 0.254 -> 0.225 ms at 30 000 rays)
-BUILDS = {"default": []}
+# "step_parallel": the same tests with every traversal in its step-parallel form (csrc/dvr_par.h: independent per-axis
+# chains, comparison-only merge, rounded-path chains) -- the arithmetic of the round-5 dvr kernels
+BUILDS = {"default": [], "step_parallel": ["-DVIDAR_MARCH_PAR"]}
 
 
 def _build(tmp_path_factory, flags):
@@ -123,3 +125,27 @@ def test_dvr_render(host, name, make, loss):
     np.testing.assert_array_equal(gt, ref[1])
     scale = max(1.0, float(np.abs(ref[2]).max()))
     np.testing.assert_allclose(grad, ref[2], rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_step_parallel_traversal_full_size_frame(tmp_path_factory):
+    """One BASELINE frame (30 000 rays from the grid centre) and a jittered-origin multi-frame set through the
+    step-parallel traversal (csrc/dvr_par.h) on the host: voxel lists and gt_dist bit-equal to the oracle, and the
+    rays really take the parallel form (the sequential march is only the fallback for irregular rays)."""
+    from vidar_amd.synthetic import ray_set
+    host = _build(tmp_path_factory, BUILDS["step_parallel"])
+    for kw in (dict(seed=0, N=1, T=1, rays_per_frame=30000),
+               dict(seed=9, N=1, T=10, rays_per_frame=1500, origin_jitter=30.0)):
+        sigma, origin, points, tindex, dims = _prep(*ray_set(**kw))
+        N, M = dims[0], dims[1]
+        ref = O.dvxlr_render(sigma, origin, points, tindex, None)
+        pred = np.empty((N, M), np.float32); gt = np.empty((N, M), np.float32)
+        dd = np.full((N, M, L), 7.0, np.float32); idx = np.full((N, M, L, 3), 7.0, np.float32)
+        est = np.zeros((N, M), np.int32)
+        before = ctypes.c_int(0); r0 = host.host_par_regular_count(ctypes.byref(before))
+        assert host.host_dvxlr_render(_p(sigma), None, _p(origin), _p(points), _p(tindex), _p(pred), _p(gt), _p(dd),
+                                      _p(idx), None, None, _p(est), *dims) == 0
+        after = ctypes.c_int(0); r1 = host.host_par_regular_count(ctypes.byref(after))
+        np.testing.assert_array_equal(idx, ref[3])
+        np.testing.assert_array_equal(gt, ref[1])
+        np.testing.assert_allclose(dd, ref[2], rtol=2e-5, atol=1e-6)
+        assert (r1 - r0) >= 0.99 * (after.value - before.value) > 0

@@ -245,11 +245,19 @@ VIDAR_DEV void decode_stash(float stash, int& count, int& k_surface, bool& nan_t
   k_surface = (v >> 11) - 1;
 }
 
-// dvxlr / dvxlr_v2 march of ray c of sample n (launch 1 of dvxlr.render, see dvr_family.hip).
+struct SequentialTraversal {
+  template <int MODE, class Sink>
+  VIDAR_DEV double run(const RayIn& r, const Vol& g, Sink& sink) const { return march<MODE>(r, g, sink); }
+};
+
+// dvxlr / dvxlr_v2 march of ray c of sample n (launch 1 of dvxlr.render, see dvr_family.hip).  `trav` is the
+// traversal that feeds the integrator: the sequential march, or (host harness only) its step-parallel form.
+template <class Trav = SequentialTraversal>
 VIDAR_DEV void dvxlr_march_ray(const float* __restrict__ sigma, const float* __restrict__ origin,
                                const float* __restrict__ points, const float* __restrict__ tindex,
                                float* __restrict__ pred_dist, float* __restrict__ gt_dist,
-                               float* __restrict__ indices, int n, int c, int M, const Vol& g) {
+                               float* __restrict__ indices, int n, int c, int M, const Vol& g,
+                               const Trav trav = Trav()) {
   constexpr int L = kDvxlrMaxD;
   const size_t row = (size_t)n * M + c;
   float* idr = indices + row * L * 3;
@@ -265,7 +273,7 @@ VIDAR_DEV void dvxlr_march_ray(const float* __restrict__ sigma, const float* __r
     const size_t vol = (size_t)g.Z * g.Y * g.X;
     Integrator<kRoundedMerged, kDvxlrMaxD, RowStager> a(sigma + ((size_t)n * g.T + r.ts) * vol, g.Y, g.X,
                                                         st);
-    const double len = march<kRoundedMerged>(r, g, a);
+    const double len = trav.template run<kRoundedMerged>(r, g, a);
     if (a.k > 0) {
       pred = (float)(a.d0 + a.S);
       gt = (float)fmin(len, a.dprev);
