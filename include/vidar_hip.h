@@ -77,6 +77,12 @@ int vidar_dvxlr_max_d(void); /* 1026, third_lib/dvxlr/dvxlr.cu:10 */
  * length before walking them; 0 = always, INT_MAX = never.  Results do not depend on it.
  * Returns the previous value. */
 int vidar_dvr_set_sort_min_waves(int min_waves);
+/* which traversal the dvr / dvxlr march launches use: -1 (default) = step-parallel kernels (independent per-axis
+ * tMax chains -- dvr.cu:232-251, dvxlr.cu:334-353 advance tMaxX only on X steps -- merged by exact comparisons,
+ * lane-per-step integration; csrc/dvr_par.h) for launches of up to 98 304 rays, lane-per-ray kernels above;
+ * 0 = always lane-per-ray, 1 = always step-parallel.  Results do not depend on it: index lists and gt_dist are
+ * bit-identical (tests/test_dvr_gpu.py runs every case under both).  Returns the previous value. */
+int vidar_dvr_set_traversal(int mode);
 /* tuning/A-B switch of dvxlr.render / render_v2: 0 = the finish pass pads the [1026] rows itself,
  * 1 (default) = one device fill ahead of the march, the finish pass only touches the live prefixes.
  * Results do not depend on it (tests/test_dvr_gpu.py runs every case under both).  Both switches are plain

@@ -13,20 +13,23 @@ pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).parent / "golden"
 
 
-PAD_MODE = {"plain": 0, "ranked": 0, "ranked-prefill": 1}
+PAD_MODE = {"plain": 0, "ranked": 0, "ranked-prefill": 1, "step-parallel": 1}
 
 
 @pytest.fixture(autouse=True, params=list(PAD_MODE))
 def march_order(request):
-    """every test runs under each launch variant: default, with the rays of each workgroup ranked
-    by estimated length (what launches above 65k rays do), and with the device-fill-first padding
-    of dvxlr.render (mode 1) -- results must not depend on it."""
+    """every test runs under each launch variant: the lane-per-ray kernels plain, with the rays of each workgroup
+    ranked by estimated length (what large launches do), and with the device-fill-first padding of dvxlr.render
+    (mode 1); and the step-parallel traversal (csrc/dvr_par.h: what launches of up to 98 304 rays use by default)
+    -- results must not depend on it."""
     from vidar_amd._lib import lib
     prev = lib().vidar_dvr_set_sort_min_waves(1 << 30 if request.param == "plain" else 0)
     prev_pad = lib().vidar_dvxlr_set_pad_mode(PAD_MODE[request.param])
+    prev_trav = lib().vidar_dvr_set_traversal(1 if request.param == "step-parallel" else 0)
     yield request.param
     lib().vidar_dvr_set_sort_min_waves(prev)
     lib().vidar_dvxlr_set_pad_mode(prev_pad)
+    lib().vidar_dvr_set_traversal(prev_trav)
 
 
 def dev(*arrs):

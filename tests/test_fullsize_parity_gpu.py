@@ -6,7 +6,8 @@ dvr/dvr.cu:87-316 and :409-626, chamferdist/knn_cpu.cpp:7-58.  Ray sets (SURVEY 
 one frame of 30 000 rays, five frames (150 000), and the OpenScene stress shape of config c4
 (T = 4 + 6 frames, 9 x 30 000 rays, origins off-centre by up to 30 voxels).  Voxel index lists,
 gt_dist, indicator and ray_pred: bit-exact; pred / dd: 2e-5 (fp64 summation order).  Every case is
-checked under the three launch variants (plain, ranked workgroups, ranked + prefill padding)."""
+checked under the four launch variants (lane-per-ray: plain, ranked workgroups, ranked + prefill padding; and the
+step-parallel traversal of csrc/dvr_par.h, which the default picks for launches of up to 98 304 rays)."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +17,7 @@ from oracle import dvr as O
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = {"plain": (1 << 30, 0), "ranked": (0, 0), "ranked-prefill": (0, 1)}
+VARIANTS = {"plain": (1 << 30, 0, 0), "ranked": (0, 0, 0), "ranked-prefill": (0, 1, 0), "step-parallel": (1 << 30, 1, 1)}
 VOXEL_M = 0.512
 SHAPES = {
     "1x30k": dict(T=1, rays_per_frame=30000, pad=0, origin_jitter=0.0),
@@ -28,13 +29,15 @@ SHAPES = {
 
 def _set_variant(name):
     from vidar_amd._lib import lib
-    thr, pad = VARIANTS[name]
-    return lib().vidar_dvr_set_sort_min_waves(thr), lib().vidar_dvxlr_set_pad_mode(pad)
+    thr, pad, trav = VARIANTS[name]
+    return (lib().vidar_dvr_set_sort_min_waves(thr), lib().vidar_dvxlr_set_pad_mode(pad),
+            lib().vidar_dvr_set_traversal(trav))
 
 
 def _restore(prev):
     from vidar_amd._lib import lib
     lib().vidar_dvr_set_sort_min_waves(prev[0]); lib().vidar_dvxlr_set_pad_mode(prev[1])
+    lib().vidar_dvr_set_traversal(prev[2])
 
 
 def _dev(*arrs):
@@ -125,7 +128,7 @@ def test_dvr_matches_oracle_at_baseline_size(shape):
     d = _dev(sigma, origin, points, tindex)
     prev = _set_variant("plain")
     try:
-        for variant in ("plain", "ranked"):
+        for variant in ("plain", "ranked", "step-parallel"):
             _set_variant(variant)
             for ph in ("train", "test"):
                 pred, gt = dvr.render_forward(*d, grid, ph)

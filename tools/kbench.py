@@ -84,6 +84,38 @@ def bench_dvr(which):
         del out, em
 
 
+def bench_dvr_trav(which):
+    """lane-per-ray kernels (traversal 0) vs the step-parallel kernels (traversal 1, csrc/dvr_par.h) per op and ray
+    count; results are identical (tests/test_dvr_gpu.py)."""
+    from vidar_amd.synthetic import ray_set
+    from vidar_amd.third_lib import dvr, dvxlr, dvxlr_v2
+    from vidar_amd._lib import lib
+    t = lambda a: torch.from_numpy(a).cuda()
+    for T, rpf in ((1, 30000), (2, 30000), (3, 30000), (5, 30000)):
+        sigma, origin, points, tindex = map(t, ray_set(seed=0, N=1, T=T, rays_per_frame=rpf))
+        N, M = tindex.shape
+        vol = sigma.numel() * 4
+        lib().vidar_dvr_set_traversal(0)
+        cnt = int(((dvxlr.render(sigma, origin, points, tindex)[3] != 0).any(-1)).sum())
+        ops = {
+            "dvr.render_forward": (lambda: dvr.render_forward(sigma, origin, points, tindex, [T, 16, 200, 200], "train"),
+                                   vol + N * M * 24 + cnt * 4),
+            "dvr.render": (lambda: dvr.render(sigma, origin, points, tindex, "l1"), 2 * vol + N * M * 24 + cnt * 12),
+            "dvxlr.render": (lambda: dvxlr.render(sigma, origin, points, tindex),
+                             vol + N * M * 16 + N * M * 4 * (2 + 1026 * 4)),
+            "dvxlr_v2.render_v2": (lambda: dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma),
+                                   2 * vol + N * M * 16 + N * M * 4 * (2 + 1026 * 6)),
+        }
+        for name, (fn, nbytes) in ops.items():
+            ms = {}
+            for trav in (0, 1):
+                lib().vidar_dvr_set_traversal(trav)
+                ms[trav] = timeit(fn, it=30)
+            report(f"{name} M={M}", ms[1], nbytes, lane_per_ray_ms=round(ms[0], 4), step_parallel_ms=round(ms[1], 4),
+                   samples=cnt)
+    lib().vidar_dvr_set_traversal(-1)
+
+
 def bench_knn(which):
     from vidar_amd.third_lib.chamferdist import knn_points
     rng = np.random.default_rng(0)

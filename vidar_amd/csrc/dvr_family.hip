@@ -32,6 +32,7 @@
 #include "vidar_hip.h"
 #include "vidar_common.h"
 #include "dvr_march.h"
+#include "dvr_par_kernels.h"
 
 namespace {
 
@@ -78,6 +79,25 @@ inline bool sort_rays(int N, int M) {
   return (long)N * ((M + kWave - 1) / kWave) > (long)g_sort_min_waves;
 }
 
+// Which traversal a launch uses: -1 (default) = the step-parallel kernels (dvr_par_kernels.h) while the launch has at
+// most kParAutoMaxRays rays -- there the lane-per-ray kernels leave most SIMDs empty and last as long as their longest
+// ray's serial chain -- and the lane-per-ray kernels above (they are the throughput-efficient form once every SIMD
+// holds several waves); 0 = always lane-per-ray, 1 = always step-parallel.
+int g_traversal = -1;
+constexpr long kParAutoMaxRays = 98304;
+inline bool step_parallel(int N, int M, const Vol& g) {
+  if (g.X > 32767 || g.Y > 32767 || g.Z > 32767) return false;      // staged voxel coordinates are int16
+  if (g_traversal >= 0) return g_traversal == 1;
+  return (long)N * M <= kParAutoMaxRays;
+}
+template <int KIND>
+inline void launch_par(const float* sigma, const float* origin, const float* points, const float* tindex,
+                       float* pred_dist, float* gt_dist, float* indices, float* grad_sigma, int N, int M,
+                       const Vol& g, int aux, hipStream_t s_) {
+  hipLaunchKernelGGL(dvr_par_kernel<KIND>, dim3((M + kParRays - 1) / kParRays, N), dim3(kParThreads), 0, s_, sigma,
+                     origin, points, tindex, pred_dist, gt_dist, indices, grad_sigma, M, g, aux);
+}
+
 // ----------------------------------------------------------------------------------------------
 // dvr.render_forward
 // ----------------------------------------------------------------------------------------------
@@ -89,35 +109,13 @@ __global__ __launch_bounds__(kBlock) void dvr_render_forward_kernel(
   const int n = blockIdx.y;
   const int c = pick_ray<kBlock>(origin, points, tindex, n, M, g);
   if (c >= M) return;
-  float pred = -1.f, gt = -1.f;
-  const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
-  if (r.valid) {
-    NoEmit ne;
-    const size_t vol = (size_t)g.Z * g.Y * g.X;
-    Integrator<kRounded, kDvrMaxD, NoEmit> integ(sigma + ((size_t)n * g.T + r.ts) * vol, g.Y, g.X, ne);
-    const double len = march<kRounded>(r, g, integ);
-    if (integ.k > 0) {
-      pred = (float)(integ.d0 + integ.S);
-      gt = (float)(train_phase ? fmin(len, integ.dprev) : len);
-    }
-  }
-  pred_dist[(size_t)n * M + c] = pred;
-  gt_dist[(size_t)n * M + c] = gt;
+  seq_forward_ray(sigma, origin, points, tindex, pred_dist, gt_dist, n, c, M, g, train_phase);
 }
 
 // ----------------------------------------------------------------------------------------------
 // dvr.render (fused loss gradient, dvr.cu:594-623).  Reference accumulates with a racy "+=";
 // we use hardware fp32 atomics, which is the race-free reading of the same sum.
 // ----------------------------------------------------------------------------------------------
-struct GradScatter {
-  float* __restrict__ grad;  // grad_sigma[n][ts] slice
-  double S_total, dl_dd;
-  __device__ __forceinline__ void commit(int, int vid, double, double dt, double P, double) {
-    const double g = dl_dd * (dt * (P - S_total));
-    if (g != 0.0) unsafeAtomicAdd(grad + vid, (float)g);
-  }
-};
-
 template <int kBlock>
 __global__ __launch_bounds__(kBlock) void dvr_render_kernel(
     const float* __restrict__ sigma, const float* __restrict__ origin,
@@ -127,30 +125,7 @@ __global__ __launch_bounds__(kBlock) void dvr_render_kernel(
   const int n = blockIdx.y;
   const int c = pick_ray<kBlock>(origin, points, tindex, n, M, g);
   if (c >= M) return;
-  float pred = -1.f, gt = -1.f;
-  const RayIn r = load_ray(origin, points, tindex, n, c, M, g);
-  if (r.valid) {
-    const size_t vol = (size_t)g.Z * g.Y * g.X;
-    const size_t slice = ((size_t)n * g.T + r.ts) * vol;
-    NoEmit ne;
-    Integrator<kClassic, kDvrMaxD, NoEmit> a(sigma + slice, g.Y, g.X, ne);
-    const double len = march<kClassic>(r, g, a);
-    if (a.k > 0) {
-      const double exp_d = a.d0 + a.S;
-      const double gt_d = fmin(len, a.dprev);
-      pred = (float)exp_d;
-      gt = (float)gt_d;
-      double dl = 1.0;
-      if (loss_type == 0) dl = (exp_d >= gt_d) ? 1.0 : -1.0;
-      else if (loss_type == 1) dl = exp_d - gt_d;
-      else if (loss_type == 2) dl = (exp_d >= gt_d) ? (1.0 / gt_d) : -(1.0 / gt_d);
-      GradScatter gs{grad_sigma + slice, a.S, dl};
-      Integrator<kClassic, kDvrMaxD, GradScatter> b(sigma + slice, g.Y, g.X, gs);
-      march<kClassic>(r, g, b);
-    }
-  }
-  pred_dist[(size_t)n * M + c] = pred;
-  gt_dist[(size_t)n * M + c] = gt;
+  seq_render_ray(sigma, origin, points, tindex, pred_dist, gt_dist, grad_sigma, n, c, M, g, loss_type);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -342,6 +317,11 @@ int vidar_dvr_set_sort_min_waves(int min_waves) {
   g_sort_min_waves = min_waves < 0 ? 0 : min_waves;
   return prev;
 }
+int vidar_dvr_set_traversal(int mode) {
+  const int prev = g_traversal;
+  g_traversal = (mode < -1 || mode > 1) ? -1 : mode;
+  return prev;
+}
 int vidar_dvxlr_max_d(void) { return kDvxlrMaxD; }
 
 int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,
@@ -352,7 +332,10 @@ int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const 
     return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
-  if (sort_rays(N, M))
+  if (step_parallel(N, M, g))
+    launch_par<kParForward>(sigma, origin, points, tindex, pred_dist, gt_dist, nullptr, nullptr, N, M, g,
+                            train_phase, (hipStream_t)stream);
+  else if (sort_rays(N, M))
     hipLaunchKernelGGL(dvr_render_forward_kernel<kSortBlock>, dim3((M + kSortBlock - 1) / kSortBlock, N),
                        dim3(kSortBlock), 0, (hipStream_t)stream, sigma, origin, points, tindex,
                        pred_dist, gt_dist, M, g, train_phase);
@@ -375,7 +358,10 @@ int vidar_dvr_render_f32(const float* sigma, const float* origin, const float* p
   if (e != hipSuccess) return (int)e;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
-  if (sort_rays(N, M))
+  if (step_parallel(N, M, g))
+    launch_par<kParRender>(sigma, origin, points, tindex, pred_dist, gt_dist, nullptr, grad_sigma, N, M, g,
+                           loss_type, (hipStream_t)stream);
+  else if (sort_rays(N, M))
     hipLaunchKernelGGL(dvr_render_kernel<kSortBlock>, dim3((M + kSortBlock - 1) / kSortBlock, N),
                        dim3(kSortBlock), 0, (hipStream_t)stream, sigma, origin, points, tindex,
                        pred_dist, gt_dist, grad_sigma, M, g, loss_type);
@@ -421,7 +407,9 @@ static int dvxlr_render_launch(bool v2, const float* sigma, const float* sigma_r
     if (e == hipSuccess) e = hipMemsetAsync(indices, 0, rows * 3 * sizeof(float), s_);
     if (e != hipSuccess) return (int)e;
   }
-  if (sort_rays(N, M))
+  if (step_parallel(N, M, g))
+    launch_par<kParDvxlr>(sigma, origin, points, tindex, pred_dist, gt_dist, indices, nullptr, N, M, g, 0, s_);
+  else if (sort_rays(N, M))
     hipLaunchKernelGGL(dvxlr_march_kernel<kSortBlock>, dim3((M + kSortBlock - 1) / kSortBlock, N),
                        dim3(kSortBlock), 0, s_, sigma, origin, points, tindex, pred_dist, gt_dist,
                        indices, M, g);
