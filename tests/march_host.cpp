@@ -146,6 +146,18 @@ int host_dvxlr_render(const float* sigma, const float* sigma_regul, const float*
   return 0;
 }
 
+// par_round_clamp (trunc + exact remainder) against the library round() it replaces; returns the mismatch count
+int host_round_clamp_mismatches(const double* p, int count, int size) {
+  int bad = 0;
+  for (int i = 0; i < count; ++i) {
+    int q = (int)round(p[i]);
+    q = q < size ? q : size - 1;
+    q = q >= 0 ? q : 0;
+    bad += (q != par_round_clamp(p[i], size)) ? 1 : 0;
+  }
+  return bad;
+}
+
 // how many of the valid rays seen by host_dvxlr_render so far were of the regular (step-parallel) class
 int host_par_regular_count(int* total) { *total = g_par_total; return g_par_regular; }
 

@@ -149,3 +149,17 @@ def test_step_parallel_traversal_full_size_frame(tmp_path_factory):
         np.testing.assert_array_equal(gt, ref[1])
         np.testing.assert_allclose(dd, ref[2], rtol=2e-5, atol=1e-6)
         assert (r1 - r0) >= 0.99 * (after.value - before.value) > 0
+
+
+def test_round_clamp_equals_library_round(tmp_path_factory):
+    """csrc/dvr_par.h par_round_clamp (trunc + exact remainder test) == clamp((int)round(p)) on half-way values, their
+    fp64 neighbours, negatives and random positions."""
+    host = _build(tmp_path_factory, BUILDS["step_parallel"])
+    rng = np.random.default_rng(0)
+    k = np.arange(-40, 440, dtype=np.float64)
+    half = np.concatenate([k + 0.5, np.nextafter(k + 0.5, np.inf), np.nextafter(k + 0.5, -np.inf), k,
+                           np.nextafter(k, np.inf), np.nextafter(k, -np.inf),
+                           np.array([0.49999999999999994, -0.49999999999999994, -0.5, -0.0, 0.0, 1e9, -1e9])])
+    p = np.ascontiguousarray(np.concatenate([half, rng.uniform(-30, 430, 200000)]))
+    for size in (1, 16, 200):
+        assert host.host_round_clamp_mismatches(_p(p), len(p), size) == 0

@@ -84,18 +84,26 @@ inline bool sort_rays(int N, int M) {
 // ray's serial chain -- and the lane-per-ray kernels above (they are the throughput-efficient form once every SIMD
 // holds several waves); 0 = always lane-per-ray, 1 = always step-parallel.
 int g_traversal = -1;
-constexpr long kParAutoMaxRays = 98304;
-inline bool step_parallel(int N, int M, const Vol& g) {
+inline bool step_parallel(int N, int M, const Vol& g, long auto_max_rays) {
   if (g.X > 32767 || g.Y > 32767 || g.Z > 32767) return false;      // staged voxel coordinates are int16
   if (g_traversal >= 0) return g_traversal == 1;
-  return (long)N * M <= kParAutoMaxRays;
+  return (long)N * M <= auto_max_rays;
 }
+// measured crossovers (profiles/r05_kbench_dvr_traversal.log): render_forward stores nothing, so its step-parallel form
+// only wins while the lane-per-ray launch is far from filling the chip; dvr.render (coalesced atomics) and the
+// one-launch dvxlr.render (padding streamed next to the march) win at every measured size
+constexpr long kParAutoForward = 24576, kParAutoRender = 1L << 40, kParAutoDvxlr = 1L << 40;
 template <int KIND>
-inline void launch_par(const float* sigma, const float* origin, const float* points, const float* tindex,
-                       float* pred_dist, float* gt_dist, float* indices, float* grad_sigma, int N, int M,
-                       const Vol& g, int aux, hipStream_t s_) {
-  hipLaunchKernelGGL(dvr_par_kernel<KIND>, dim3((M + kParRays - 1) / kParRays, N), dim3(kParThreads), 0, s_, sigma,
-                     origin, points, tindex, pred_dist, gt_dist, indices, grad_sigma, M, g, aux);
+inline void launch_par(const float* sigma, const float* sigma_regul, const float* origin, const float* points,
+                       const float* tindex, float* pred_dist, float* gt_dist, float* dd_dsigma, float* indices,
+                       float* ray_pred, float* indicator, float* grad_sigma, int N, int M, const Vol& g, int aux,
+                       hipStream_t s_) {
+  // dvxlr: the second half of the grid are the padding workgroups (dvr_par_kernels.h)
+  const int nb = (M + kParRays - 1) / kParRays;
+  const bool rows = (KIND == kParDvxlr || KIND == kParDvxlrV2);
+  hipLaunchKernelGGL(dvr_par_kernel<KIND>, dim3(rows ? 2 * nb : nb, N), dim3(kParThreads), 0, s_, sigma,
+                     sigma_regul, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices, ray_pred, indicator,
+                     grad_sigma, M, g, aux);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -169,48 +177,17 @@ __global__ __launch_bounds__(256) void dvxlr_finish_kernel(
   float* rpr = V2 ? ray_pred + row * L : nullptr;
   float* inr = V2 ? indicator + row * L : nullptr;
 
-  int cnt, ks;
-  bool nan_tail;
-  decode_stash(idr[2], cnt, ks, nan_tail);
   const float* reg = nullptr;
-  if (V2 && cnt > 0) {
-    const long ti = (long)tindex[row];          // a ray with samples has a valid time index
-    reg = sigma_regul + ((size_t)n * g.T + (g.T == 1 ? 0 : ti)) * ((size_t)g.Z * g.Y * g.X);
-  }
-
-  // chunks of 64 samples from the far end; a lane only touches the slots of its own sample.
-  // W_k sits in sample k+1's slot: neighbour lane, or lane 0 of the chunk handled just before.
-  double carry = nan_tail ? (double)NAN : 0.0;
-  float w_above = 0.f;
-  for (int base = cnt > 0 ? ((cnt - 1) / kWave) * kWave : -1; base >= 0; base -= kWave) {
-    const int k = base + lane;
-    Parked p{0.f, 0.f, 0.f};
-    if (k < cnt) p = reinterpret_cast<const Parked*>(idr)[k];
-    float w = __shfl_down(p.w_prev, 1, kWave);
-    if (lane == kWave - 1) w = w_above;
-    w_above = __shfl(p.w_prev, 0, kWave);
-    double sfx = (k < cnt - 1) ? (double)w : 0.0;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const double t = __shfl_down(sfx, off, kWave);
-      if (lane + off < kWave) sfx += t;
-    }
-    const double R = sfx + carry;
-    carry += __shfl(sfx, 0, kWave);
-    if (k < cnt) {
-      const int vid = (int)p.vid;
-      const int zy = vid / g.X, x = vid - zy * g.X;
-      const int z = zy / g.Y, y = zy - z * g.Y;
-      ddr[k] = (float)(-(double)p.dt * R);
-      idr[3 * k + 0] = (float)z;
-      idr[3 * k + 1] = (float)y;
-      idr[3 * k + 2] = (float)x;
-      if (V2) {
-        rpr[k] = reg[vid];
-        inr[k] = (k == ks) ? 1.f : 0.f;
-      }
+  if (V2) {
+    int cnt0, ks0;
+    bool nt0;
+    decode_stash(idr[2], cnt0, ks0, nt0);
+    if (cnt0 > 0) {
+      const long ti = (long)tindex[row];          // a ray with samples has a valid time index
+      reg = sigma_regul + ((size_t)n * g.T + (g.T == 1 ? 0 : ti)) * ((size_t)g.Z * g.Y * g.X);
     }
   }
+  const int cnt = dvxlr_finish_row<V2>(reg, ddr, idr, rpr, inr, g, lane);
 
   if (!PAD) return;
   // padding: one odd element if needed, then 8-byte stores
@@ -332,9 +309,9 @@ int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const 
     return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
-  if (step_parallel(N, M, g))
-    launch_par<kParForward>(sigma, origin, points, tindex, pred_dist, gt_dist, nullptr, nullptr, N, M, g,
-                            train_phase, (hipStream_t)stream);
+  if (step_parallel(N, M, g, kParAutoForward))
+    launch_par<kParForward>(sigma, nullptr, origin, points, tindex, pred_dist, gt_dist, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, N, M, g, train_phase, (hipStream_t)stream);
   else if (sort_rays(N, M))
     hipLaunchKernelGGL(dvr_render_forward_kernel<kSortBlock>, dim3((M + kSortBlock - 1) / kSortBlock, N),
                        dim3(kSortBlock), 0, (hipStream_t)stream, sigma, origin, points, tindex,
@@ -358,9 +335,9 @@ int vidar_dvr_render_f32(const float* sigma, const float* origin, const float* p
   if (e != hipSuccess) return (int)e;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
-  if (step_parallel(N, M, g))
-    launch_par<kParRender>(sigma, origin, points, tindex, pred_dist, gt_dist, nullptr, grad_sigma, N, M, g,
-                           loss_type, (hipStream_t)stream);
+  if (step_parallel(N, M, g, kParAutoRender))
+    launch_par<kParRender>(sigma, nullptr, origin, points, tindex, pred_dist, gt_dist, nullptr, nullptr, nullptr,
+                           nullptr, grad_sigma, N, M, g, loss_type, (hipStream_t)stream);
   else if (sort_rays(N, M))
     hipLaunchKernelGGL(dvr_render_kernel<kSortBlock>, dim3((M + kSortBlock - 1) / kSortBlock, N),
                        dim3(kSortBlock), 0, (hipStream_t)stream, sigma, origin, points, tindex,
@@ -398,6 +375,17 @@ static int dvxlr_render_launch(bool v2, const float* sigma, const float* sigma_r
     return VIDAR_ERR_BAD_ARG;
   if (N == 0 || M == 0) return 0;
   Vol g{T, TO, Z, Y, X};
+  // one launch: padding, march and row finish in the step-parallel kernel (float4 fills need 16-byte aligned rows)
+  if (step_parallel(N, M, g, kParAutoDvxlr) &&
+      (((uintptr_t)dd_dsigma | (uintptr_t)indices | (uintptr_t)ray_pred | (uintptr_t)indicator) & 15u) == 0) {
+    if (v2)
+      launch_par<kParDvxlrV2>(sigma, sigma_regul, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices,
+                              ray_pred, indicator, nullptr, N, M, g, 0, s_);
+    else
+      launch_par<kParDvxlr>(sigma, nullptr, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices, nullptr,
+                            nullptr, nullptr, N, M, g, 0, s_);
+    return vidar_last_error();
+  }
   if (g_dvxlr_pad_mode != 0) {
     const size_t rows = (size_t)N * M * kDvxlrMaxD;
     hipError_t e = hipMemsetAsync(dd_dsigma, 0, rows * sizeof(float), s_);
@@ -407,9 +395,7 @@ static int dvxlr_render_launch(bool v2, const float* sigma, const float* sigma_r
     if (e == hipSuccess) e = hipMemsetAsync(indices, 0, rows * 3 * sizeof(float), s_);
     if (e != hipSuccess) return (int)e;
   }
-  if (step_parallel(N, M, g))
-    launch_par<kParDvxlr>(sigma, origin, points, tindex, pred_dist, gt_dist, indices, nullptr, N, M, g, 0, s_);
-  else if (sort_rays(N, M))
+  if (sort_rays(N, M))
     hipLaunchKernelGGL(dvxlr_march_kernel<kSortBlock>, dim3((M + kSortBlock - 1) / kSortBlock, N),
                        dim3(kSortBlock), 0, s_, sigma, origin, points, tindex, pred_dist, gt_dist,
                        indices, M, g);

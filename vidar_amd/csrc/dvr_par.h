@@ -104,15 +104,21 @@ VIDAR_DEV int par_rank(const ParRay& P, int a, int i, double t, const double* co
       double x = (t - P.ax[b].tmax) * inv;                      // estimate of the boundary, corrected below
       if (!(x > -1.0)) x = -1.0;
       if (x > (double)m) x = (double)m;
-      j = (int)x + 1;
+      j = (int)floor(x) + 1;                                    // floor, not truncation: x in (-1, 0) means "before all"
       j = j < 0 ? 0 : (j > m ? m : j);
       const double* s = tb[b];
+      // both neighbours of the estimated boundary are requested at once; the loops only run when it is off
+      const double lo = (j > 0) ? s[j - 1] : -DBL_MAX, hi = (j < m) ? s[j] : DBL_MAX;
       if (b > a) {
-        while (j < m && s[j] <= t) ++j;
-        while (j > 0 && !(s[j - 1] <= t)) --j;
+        if (!((lo <= t || j == 0) && (!(hi <= t) || j == m))) {
+          while (j < m && s[j] <= t) ++j;
+          while (j > 0 && !(s[j - 1] <= t)) --j;
+        }
       } else {
-        while (j < m && s[j] < t) ++j;
-        while (j > 0 && !(s[j - 1] < t)) --j;
+        if (!((lo < t || j == 0) && (!(hi < t) || j == m))) {
+          while (j < m && s[j] < t) ++j;
+          while (j > 0 && !(s[j - 1] < t)) --j;
+        }
       }
     }
     before[b] = j;
@@ -135,8 +141,14 @@ VIDAR_DEV bool par_steps(const ParRay& P, const int last_rank[3], int& S) {
   return true;
 }
 
+// clamp((int)round(p), 0, size - 1) with round() = half away from zero, written as trunc + an exact remainder test
+// (p - trunc(p) is exact in fp64): a handful of instructions instead of the library call in the serial chain.
+// |p| stays far below 2^31 on a regular ray.  tests/test_march_host_cpu.py checks it against round().
 VIDAR_DEV int par_round_clamp(double p, int size) {
-  int q = (int)round(p);
+  const double t = trunc(p);
+  const double f = p - t;
+  int q = (int)t;
+  if (fabs(f) >= 0.5) q += (p < 0.0) ? -1 : 1;
   q = q < size ? q : size - 1;
   return q >= 0 ? q : 0;
 }
