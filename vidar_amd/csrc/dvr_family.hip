@@ -28,6 +28,7 @@
 //    estimate of the step count and hand each wave one quartile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "vidar_hip.h"
 #include "vidar_common.h"
@@ -84,6 +85,10 @@ inline bool sort_rays(int N, int M) {
 // ray's serial chain -- and the lane-per-ray kernels above (they are the throughput-efficient form once every SIMD
 // holds several waves); 0 = always lane-per-ray, 1 = always step-parallel.
 int g_traversal = -1;
+// persistent padding workgroups of the one-launch dvxlr.render / render_v2: enough of them to finish the rows' padding
+// when the compute workgroups finish the march (one streams ~40-50 GB/s; sweeps 16 ... 1024 in
+// profiles/r05_kbench_dvr_traversal.log: fewer leave the call waiting for the padding, more take wave slots from the march)
+constexpr int kParPadWgs = 80, kParPadWgsV2 = 128;
 inline bool step_parallel(int N, int M, const Vol& g, long auto_max_rays) {
   if (g.X > 32767 || g.Y > 32767 || g.Z > 32767) return false;      // staged voxel coordinates are int16
   if (g_traversal >= 0) return g_traversal == 1;
@@ -98,12 +103,13 @@ inline void launch_par(const float* sigma, const float* sigma_regul, const float
                        const float* tindex, float* pred_dist, float* gt_dist, float* dd_dsigma, float* indices,
                        float* ray_pred, float* indicator, float* grad_sigma, int N, int M, const Vol& g, int aux,
                        hipStream_t s_) {
-  // dvxlr: the second half of the grid are the padding workgroups (dvr_par_kernels.h)
+  // dvxlr: the first pad_wgs workgroups of every grid row are the persistent padding workgroups (dvr_par_kernels.h)
   const int nb = (M + kParRays - 1) / kParRays;
   const bool rows = (KIND == kParDvxlr || KIND == kParDvxlrV2);
-  hipLaunchKernelGGL(dvr_par_kernel<KIND>, dim3(rows ? 2 * nb : nb, N), dim3(kParThreads), 0, s_, sigma,
+  const int pad_wgs = rows ? std::min(KIND == kParDvxlrV2 ? kParPadWgsV2 : kParPadWgs, (M + 63) / 64) : 0;
+  hipLaunchKernelGGL(dvr_par_kernel<KIND>, dim3(nb + pad_wgs, N), dim3(kParThreads), 0, s_, sigma,
                      sigma_regul, origin, points, tindex, pred_dist, gt_dist, dd_dsigma, indices, ray_pred, indicator,
-                     grad_sigma, M, g, aux);
+                     grad_sigma, M, g, aux, pad_wgs);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -299,6 +305,17 @@ int vidar_dvr_set_traversal(int mode) {
   g_traversal = (mode < -1 || mode > 1) ? -1 : mode;
   return prev;
 }
+#ifdef VIDAR_PAR_TIMING
+int vidar_dbg_par_cycles(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(vidar_march::g_par_cycles), sizeof(unsigned long long) * 8);
+  if (reset) {
+    unsigned long long z[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(vidar_march::g_par_cycles), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 int vidar_dvxlr_max_d(void) { return kDvxlrMaxD; }
 
 int vidar_dvr_render_forward_f32(const float* sigma, const float* origin, const float* points,

@@ -101,9 +101,10 @@ template <int MODE, int EMIT, bool V2>
 __device__ __forceinline__ ParResult par_consume(const double* __restrict__ md, const short* __restrict__ qb, int S,
                                                  const float* __restrict__ sig, const Vol& g, double true_len,
                                                  const RowsOut& rows, float* __restrict__ grad, double S_total,
-                                                 double dl_dd, int lane) {
+                                                 double dl_dd, int lane, float pre0, float pre1) {
   constexpr bool kMerged = (MODE == kRoundedMerged);
   int k_base = 0;
+  float c_sg = 0.f;
   double csd_c = 0.0, T_c = 1.0, dl_c = 0.0, d0 = 0.0, P_c = 0.0;
   bool has_carry = false;
   int c_vid = 0, c_qx = 0, c_qy = 0, c_qz = 0;
@@ -117,10 +118,15 @@ __device__ __forceinline__ ParResult par_consume(const double* __restrict__ md, 
     const bool valid = (lane == 0) ? has_carry : (s < S);
     int vid = c_vid, qx = c_qx, qy = c_qy, qz = c_qz;
     double d = c_d, lastd = 0.0, udt = c_udt;
+    // densities of the first two chunks were requested before the wave started on its rays (a gather round trip per
+    // chunk in the middle of the scans was the largest single cost of this phase); later chunks load here
+    float sg = (sb == 0) ? pre0 : (sb == 63 ? pre1 : 0.f);
+    if (lane == 0) sg = c_sg;
     if (lane > 0 && valid) {
       const short4 q = reinterpret_cast<const short4*>(qb)[s];
       qx = q.x; qy = q.y; qz = q.z;
       vid = (qz * g.Y + qy) * g.X + qx;
+      if (sb > 63) sg = sig[vid];
       d = md[s];
       lastd = (s > 0) ? md[s - 1] : 0.0;
       udt = fmax(0.0, d - lastd);
@@ -144,8 +150,6 @@ __device__ __forceinline__ ParResult par_consume(const double* __restrict__ md, 
     const bool commit = valid && ((lane == last_lane) ? done : (same_dn == 0));
     const unsigned long long cm = __ballot(commit);
     const int kl = k_base + __popcll(cm & lt);
-    float sg = 0.f;
-    if (commit) sg = sig[vid];
     const double sd = commit ? (double)sg * udt : 0.0;
     const double csd = csd_c + wave_scan_f64(sd);
     const double T = (double)expf((float)(-csd));
@@ -188,6 +192,7 @@ __device__ __forceinline__ ParResult par_consume(const double* __restrict__ md, 
     has_carry = !done;
     if (!done) {
       c_vid = __builtin_amdgcn_readlane(vid, 63);
+      c_sg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sg), 63));
       c_d = readlane_f64(d, 63);
       c_udt = readlane_f64(udt, 63);
       if (EMIT == kEmitRows) {   // the carried sample's coordinates travel with it
@@ -208,6 +213,58 @@ __device__ __forceinline__ ParResult par_consume(const double* __restrict__ md, 
   R.d0 = d0;
   R.S = P_c;
   R.dprev = dl_c;
+  return R;
+}
+
+// inclusive wave sum at every lane -> total at lane 63 (fp64, DPP)
+__device__ __forceinline__ double wave_total_f64(double v) { return readlane_f64(wave_scan_f64(v), 63); }
+
+// Lean lane-per-step integrator of the modes WITHOUT the duplicate merge (dvr.render_forward, dvr.render): every step
+// is a sample, so lane = step, the neighbouring distances come straight from LDS and nothing is carried between
+// chunks except the running optical depth:  W_s = exp(-csd_s) (d_{s+1} - d_s),  pred = d_0 + sum_s W_s.
+//   SCATTER: second pass of dvr.render -- grad[voxel_s] += dl_dd * dt_s * (P_s - S_total), P_s = sum_{j < s} W_j
+template <bool SCATTER>
+__device__ __forceinline__ ParResult par_consume_plain(const double* __restrict__ md, const short* __restrict__ qb,
+                                                       int S, const float* __restrict__ sig, const Vol& g,
+                                                       float* __restrict__ grad, double S_total, double dl_dd,
+                                                       int lane, float pre0, float pre1) {
+  double csd_c = 0.0, acc = 0.0, P_c = 0.0;
+  for (int sb = 0; sb < S; sb += 64) {
+    const int s = sb + lane;
+    const bool valid = s < S;
+    double d = 0.0, dp = 0.0, dn = 0.0;
+    float sg = 0.f;
+    int vid = 0;
+    if (valid) {
+      const short4 q = reinterpret_cast<const short4*>(qb)[s];
+      vid = ((int)q.z * g.Y + (int)q.y) * g.X + (int)q.x;
+      sg = (sb == 0) ? pre0 : (sb == 64 ? pre1 : sig[vid]);     // first two chunks: requested ahead (see the kernel)
+      d = md[s];
+      dp = (s > 0) ? md[s - 1] : 0.0;
+      dn = (s + 1 < S) ? md[s + 1] : d;
+    }
+    const double dt = fmax(0.0, d - dp);
+    const double csd = csd_c + wave_scan_f64(valid ? (double)sg * dt : 0.0);
+    const double T = (double)expf((float)(-csd));
+    const double w = valid ? T * (dn - d) : 0.0;              // W_s; 0 for the last sample (dn == d)
+    if (SCATTER) {
+      const double incl = wave_scan_f64(w);
+      const double P = P_c + (incl - w);                      // exclusive: sum_{j < s} W_j
+      if (valid) {
+        const double gr = dl_dd * (dt * (P - S_total));
+        if (gr != 0.0) unsafeAtomicAdd(grad + vid, (float)gr);
+      }
+      P_c += readlane_f64(incl, 63);
+    } else {
+      acc += w;
+    }
+    csd_c = readlane_f64(csd, 63);
+  }
+  ParResult R;
+  R.count = S;
+  R.d0 = md[0];
+  R.dprev = md[S - 1];
+  R.S = SCATTER ? P_c : wave_total_f64(acc);
   return R;
 }
 
@@ -341,6 +398,20 @@ __device__ __forceinline__ void wave_fill(float* __restrict__ base, size_t a, si
   if (b4 + lane < b) base[b4 + lane] = val;
 }
 
+#ifdef VIDAR_PAR_TIMING   // experiment only: cycles per phase, summed over workgroups (wave 0)
+__device__ unsigned long long g_par_cycles[8];
+#define PAR_STAMP(i)                                                       \
+  do {                                                                     \
+    if (tid == 0) {                                                        \
+      const unsigned long long now_ = __builtin_readcyclecounter();        \
+      atomicAdd(&g_par_cycles[i], now_ - stamp_);                          \
+      stamp_ = now_;                                                       \
+    }                                                                      \
+  } while (0)
+#else
+#define PAR_STAMP(i) do {} while (0)
+#endif
+
 // grid (ceil(M / kParRays), N), block kParThreads.  `aux`: train_phase (forward) / loss_type (render).
 template <int KIND>
 __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
@@ -348,7 +419,7 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
     const float* __restrict__ points, const float* __restrict__ tindex, float* __restrict__ pred_dist,
     float* __restrict__ gt_dist, float* __restrict__ dd_dsigma, float* __restrict__ indices,
     float* __restrict__ ray_pred, float* __restrict__ indicator, float* __restrict__ grad_sigma, int M, Vol g,
-    int aux) {
+    int aux, int pad_wgs) {
   constexpr int MODE = ParMode<KIND>::mode;
   constexpr bool kRows = (KIND == kParDvxlr || KIND == kParDvxlrV2);
   constexpr bool V2 = (KIND == kParDvxlrV2);
@@ -358,39 +429,47 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
   const int n = blockIdx.y;
   const size_t vol = (size_t)g.Z * g.Y * g.X;
 
-  // ---- one-launch dvxlr: the second half of the grid only PADS.  Workgroup nb + b writes the zeros / -1 of the rows
-  // of workgroup b's rays from each ray's element bound (the same par_setup, so the two never touch the same
-  // bytes) to the row end: 95 % of the call's bytes stream at fill rate next to the compute workgroups, sharing no
-  // barrier with them (filling from the compute workgroups' idle waves serialised behind their barriers) ----
-  if (kRows && (int)blockIdx.x >= (int)gridDim.x / 2) {
-    const int c0f = ((int)blockIdx.x - (int)gridDim.x / 2) * kParRays;
-    const int nrows = min(kParRays, M - c0f);
+  // ---- one-launch dvxlr: the FIRST `pad_wgs` workgroups of the grid (about one per CU, dispatched first) only PAD,
+  // persistently: each walks blocks of 64 rays and writes the zeros / -1 of their rows from each ray's element bound
+  // (the same par_setup as the compute workgroups, so the two never touch the same bytes) to the row end.  95 % of
+  // the call's bytes stream at fill rate for the whole launch while the compute workgroups, which share no barrier
+  // with them, take the remaining wave slots.  (Measured alternatives: padding from the compute workgroups' idle
+  // waves serialises behind their barriers; one padding workgroup per compute workgroup takes half the wave slots;
+  // padding workgroups at the end of the grid run after the march -- profiles/r05_kbench_dvr_traversal.log) ----
+  if (kRows && (int)blockIdx.x < pad_wgs) {
     int* bound = reinterpret_cast<int*>(st.seq);
-    if (tid < nrows) {
-      const RayIn rf = load_ray(origin, points, tindex, n, c0f + tid, M, g);
-      const ParRay F = par_setup<MODE>(rf, g);
-      // regular ray: from its element bound.  Padded ray (no samples): the whole row (the compute workgroup only
-      // stores the same 0.0 stash into it).  Valid but irregular ray: nothing -- its row belongs to the compute
-      // workgroup's sequential fallback, which pads it itself.
-      bound[tid] = F.regular ? F.elems : (rf.valid ? L : 0);
-    }
-    __syncthreads();
-    const size_t row0 = (size_t)n * M + c0f;
-    constexpr int U = V2 ? 6 : 4;      // units of about one [1026] row: dd | indices in thirds | ray_pred | indicator
-    for (int j = wave; j < nrows * U; j += kParThreads / 64) {
-      const int r = j / U, u = j - r * U;
-      const size_t e = (size_t)bound[r];
-      const size_t row = row0 + r;
-      if (u == 0) wave_fill(dd_dsigma, row * L + e, (row + 1) * L, 0.f, lane);
-      else if (u <= 3) {
-        const size_t a = (row * L + e) * 3, b = (row + 1) * L * 3, third = (b - a) / 3;
-        wave_fill(indices, a + (u - 1) * third, u == 3 ? b : a + u * third, 0.f, lane);
-      } else if (u == 4) wave_fill(ray_pred, row * L + e, (row + 1) * L, 0.f, lane);
-      else wave_fill(indicator, row * L + e, (row + 1) * L, -1.f, lane);
+    const int nblk = (M + 63) / 64;
+    for (int blk = (int)blockIdx.x; blk < nblk; blk += pad_wgs) {
+      const int c0f = blk * 64;
+      const int nrows = min(64, M - c0f);
+      if (tid < nrows) {
+        const RayIn rf = load_ray(origin, points, tindex, n, c0f + tid, M, g);
+        const ParRay F = par_setup<MODE>(rf, g);
+        // regular ray: from its element bound.  Padded ray (no samples): the whole row (the compute workgroup only
+        // stores the same 0.0 stash into it).  Valid but irregular ray: nothing -- its row belongs to the compute
+        // workgroup's sequential fallback, which pads it itself.
+        bound[tid] = F.regular ? F.elems : (rf.valid ? L : 0);
+      }
+      __syncthreads();
+      const size_t row0 = (size_t)n * M + c0f;
+      for (int r = wave; r < nrows; r += kParThreads / 64) {      // a wave pads whole rows
+        const size_t e = (size_t)bound[r];
+        const size_t row = row0 + r;
+        wave_fill(dd_dsigma, row * L + e, (row + 1) * L, 0.f, lane);
+        wave_fill(indices, (row * L + e) * 3, (row + 1) * L * 3, 0.f, lane);
+        if (V2) {
+          wave_fill(ray_pred, row * L + e, (row + 1) * L, 0.f, lane);
+          wave_fill(indicator, row * L + e, (row + 1) * L, -1.f, lane);
+        }
+      }
+      __syncthreads();
     }
     return;
   }
-  const int c0 = blockIdx.x * kParRays;
+  const int c0 = ((int)blockIdx.x - (kRows ? pad_wgs : 0)) * kParRays;
+#ifdef VIDAR_PAR_TIMING
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
 
   // ---- setup: lane (ray, axis); every lane evaluates the whole ray (its own axis stays in registers) ----
   const int cr = tid / 3, ca = tid - 3 * cr;
@@ -420,6 +499,7 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
   }
   if (tid == 0) st.first = 0;
   __syncthreads();
+  PAR_STAMP(0);
 
   // this lane's own axis as scalars (a run-time index into P.ax[] would push the struct into scratch)
   const int size_a = (ca == 0) ? g.X : (ca == 1 ? g.Y : g.Z);
@@ -456,6 +536,7 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
       for (int i = 0; i < my_m; ++i) { out[i] = t; t += my_tdelta; }
     }
     __syncthreads();
+    PAR_STAMP(1);
 
     // ---- rank: every element finds its merged position ----
     for (int r = first + wave; r < end; r += kParThreads / 64) {
@@ -483,6 +564,7 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
       }
     }
     __syncthreads();
+    PAR_STAMP(2);
 
     // ---- step count, bound check, chain 2: rounded-path voxel coordinates per step ----
     if (mine) {
@@ -522,11 +604,37 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
       }
     }
     __syncthreads();
+    PAR_STAMP(3);
 
-    // ---- consume: wave per ray, lane per step ----
-    for (int r = first + wave; r < end; r += kParThreads / 64) {
+    // ---- consume: wave per ray, lane per step.  First the density gathers of the first two chunks of all (up to 4)
+    // rays of this wave are put in flight together ----
+    constexpr int kChunk = (MODE == kRoundedMerged) ? 63 : 64;
+    float pre[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pre[k][0] = 0.f; pre[k][1] = 0.f;
+      const int r = first + wave + 4 * k;
+      if (r < end && st.hdr[r].state == 0) {
+        const ParHdr& h = st.hdr[r];
+        const float* sig = sigma + ((size_t)n * g.T + h.ts) * vol;
+        const short4* qv = (MODE == kClassic) ? reinterpret_cast<const short4*>(st.vox + h.off)
+                                              : reinterpret_cast<const short4*>(st.seq + h.off);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int s = cc * kChunk + lane - (kChunk == 63 ? 1 : 0);
+          if (s >= 0 && s < h.S) {
+            const short4 q = qv[s];
+            pre[k][cc] = sig[((int)q.z * g.Y + (int)q.y) * g.X + (int)q.x];
+          }
+        }
+      }
+    }
+    int kk = 0;
+    for (int r = first + wave; r < end; r += kParThreads / 64, ++kk) {
       ParHdr& h = st.hdr[r];
       if (h.state != 0) continue;
+      const float pre0 = kk == 0 ? pre[0][0] : (kk == 1 ? pre[1][0] : (kk == 2 ? pre[2][0] : pre[3][0]));
+      const float pre1 = kk == 0 ? pre[0][1] : (kk == 1 ? pre[1][1] : (kk == 2 ? pre[2][1] : pre[3][1]));
       const int c = c0 + r;
       const size_t row = (size_t)n * M + c;
       const float* sig = sigma + ((size_t)n * g.T + h.ts) * vol;
@@ -538,7 +646,7 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
       float pred = -1.f, gt = -1.f;
       RowsOut none{};
       if (KIND == kParForward) {
-        const ParResult R = par_consume<MODE, kEmitNone, false>(dm, qb, S, sig, g, len, none, nullptr, 0.0, 0.0, lane);
+        const ParResult R = par_consume_plain<false>(dm, qb, S, sig, g, nullptr, 0.0, 0.0, lane, pre0, pre1);
         if (R.count > 0) {
           pred = (float)(R.d0 + R.S);
           gt = (float)(aux ? fmin(len, R.dprev) : len);
@@ -550,22 +658,23 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
         ro.reg = V2 ? sigma_regul + ((size_t)n * g.T + h.ts) * vol : nullptr;
         ro.pad_to = h.elems;
         double St = 0.0;
-        if (S > 63) St = par_consume<MODE, kEmitNone, false>(dm, qb, S, sig, g, len, none, nullptr, 0.0, 0.0, lane).S;
-        const ParResult R = par_consume<MODE, kEmitRows, V2>(dm, qb, S, sig, g, len, ro, nullptr, St, 0.0, lane);
+        if (S > 63)
+          St = par_consume<MODE, kEmitNone, false>(dm, qb, S, sig, g, len, none, nullptr, 0.0, 0.0, lane, pre0, pre1).S;
+        const ParResult R = par_consume<MODE, kEmitRows, V2>(dm, qb, S, sig, g, len, ro, nullptr, St, 0.0, lane, pre0,
+                                                              pre1);
         if (R.count > 0) {
           pred = (float)(R.d0 + R.S);
           gt = (float)fmin(len, R.dprev);
         }
       } else {
-        const ParResult R = par_consume<MODE, kEmitNone, false>(dm, qb, S, sig, g, len, none, nullptr, 0.0, 0.0, lane);
+        const ParResult R = par_consume_plain<false>(dm, qb, S, sig, g, nullptr, 0.0, 0.0, lane, pre0, pre1);
         if (R.count > 0) {
           const double exp_d = R.d0 + R.S;
           const double gt_d = fmin(len, R.dprev);
           pred = (float)exp_d;
           gt = (float)gt_d;
           float* grad = grad_sigma + ((size_t)n * g.T + h.ts) * vol;
-          par_consume<MODE, kEmitScatter, false>(dm, qb, S, sig, g, len, none, grad, R.S,
-                                                 dvr_loss_slope(aux, exp_d, gt_d), lane);
+          par_consume_plain<true>(dm, qb, S, sig, g, grad, R.S, dvr_loss_slope(aux, exp_d, gt_d), lane, pre0, pre1);
         }
       }
       if (lane == 0) {
@@ -575,8 +684,8 @@ __global__ __launch_bounds__(kParThreads) void dvr_par_kernel(
       }
     }
     __syncthreads();
+    PAR_STAMP(4);
     if (tid == 0) st.first = end;
-
     __syncthreads();
   }
   // ---- sequential fallback: one lane per irregular ray ----
