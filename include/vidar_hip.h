@@ -102,11 +102,16 @@ int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float*
                            void* stream);
 
 /* dvxlr.get_grad_sigma(elementwise_mult, indices, tindex, sigma_like) -> [grad_sigma]
- * third_lib/dvxlr/dvxlr.cu:63-156.  L = elementwise_mult.size(2). grad_sigma zeroed by the call. */
+ * third_lib/dvxlr/dvxlr.cu:63-156.  L = elementwise_mult.size(2). grad_sigma zeroed by the call.
+ * `workspace` (vidar_dvxlr_get_grad_sigma_workspace_bytes; the v1 call needs half of it): caller-owned device
+ * scratch for 8 private copies of the gradient volume -- the rays of a frame share their first voxels, whose
+ * atomics otherwise serialise (one frame of 30 000 rays took as long as five); NULL = add straight into grad_sigma. */
+size_t vidar_dvxlr_get_grad_sigma_workspace_bytes(int N, int T, int Z, int Y, int X);
 int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult /*[N,M,L]*/,
                                    const float* indices /*[N,M,L,3]*/, const float* tindex,
                                    float* grad_sigma /*[N,T,Z,Y,X]*/, int N, int M, int L, int T,
-                                   int Z, int Y, int X, void* stream);
+                                   int Z, int Y, int X, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 
 /* dvxlr_v2.render_v2(sigma, origin, points, tindex, sigma_regul)
  *   -> [pred_dist, gt_dist, dd_dsigma, indices, ray_pred, indicator]
@@ -124,7 +129,7 @@ int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* 
                                     const float* tindex, const float* indicator,
                                     const float* grad_ray_pred, float* grad_sigma,
                                     float* grad_sigma_regul, int N, int M, int L, int T, int Z, int Y,
-                                    int X, void* stream);
+                                    int X, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * third_lib/chamfer_dist/chamferdist  (pybind surface: chamferdist/ext.cpp:5-11)
@@ -259,13 +264,16 @@ int vidar_sca_combine_f32(const float* src, const int32_t* slot_of, const float*
  * step = grid_step / (min(H,W)//2) rounded to f32 (:102-104); act: 0 = 'sigmoid', 1 = 'exp' (:117-123).
  *   prob   : occ logits -> path_prob = prod_{k<G,valid}(1 - act(occ(n_k))) * act(occ(n_cell))   (:96-129)
  *   gather : feat = sum_k a(n_k) m_k / (sum_k m_k + eps), m_k = path_prob(n_k)*valid2_k          (:131-150)
- * Backward entry points zero their gradient outputs and accumulate with fp32 atomics.
+ * Backward entry points zero their gradient outputs and accumulate with fp32 atomics; `workspace`
+ * (vidar_latent_render_bwd_workspace_bytes, caller-owned scratch, 16-byte aligned) holds 8 private copies of the
+ * gradient maps as for the ray ops below, NULL = add straight into the outputs.
  * ------------------------------------------------------------------------- */
+size_t vidar_latent_render_bwd_workspace_bytes(int bs, int H, int W, int Z);
 int vidar_latent_render_prob_fwd_f32(const float* occ, float* path_prob, int bs, int H, int W, int Z,
                                      int grid_num, float step, int act, void* stream);
 int vidar_latent_render_prob_bwd_f32(const float* occ, const float* grad_path_prob, float* grad_occ,
                                      int bs, int H, int W, int Z, int grid_num, float step, int act,
-                                     void* stream);
+                                     void* workspace, size_t workspace_bytes, void* stream);
 int vidar_latent_render_gather_fwd_f32(const float* path_prob, const float* lora_a, float* feat,
                                        float* msum, int bs, int H, int W, int Z, int grid_num,
                                        float step, float eps, void* stream);
@@ -273,7 +281,7 @@ int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora
                                        const float* msum, const float* grad_feat,
                                        float* grad_path_prob, float* grad_lora_a, int bs, int H,
                                        int W, int Z, int grid_num, float step, float eps,
-                                       void* stream);
+                                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * ViDAR head ray-march over the predicted occupancy volume (fused).  Replaces the torch op chains
@@ -288,15 +296,20 @@ int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora
  *             end point lies strictly inside the volume (others are dropped, :464-467); lse saved.
  *   dist[r] = ((1-pn)+pn) * pd, pd = length of argmax_k(logit_k + noise[r,k]),
  *             pn = softmax mass of waypoints farther than pd;  aux[r] = {pd, pn, lse}.
- * Backward entry points zero grad_sigma and accumulate with fp32 atomics.
+ * Backward entry points zero grad_sigma and accumulate with fp32 atomics.  All rays of a frame start at the sensor
+ * origin, so the first waypoints' atomics serialise on a few hundred addresses: given a `workspace` of
+ * vidar_ray_bwd_workspace_bytes(F,Z,Y,X) bytes (caller-owned device scratch on the call's device / stream, nothing
+ * survives the call) the kernels add into 8 private copies of the volume that a second kernel sums; with
+ * workspace == NULL they add straight into grad_sigma.  Results agree to fp32 summation order.
  * ------------------------------------------------------------------------- */
+size_t vidar_ray_bwd_workspace_bytes(int F, int Z, int Y, int X);
 int vidar_ray_ce_fwd_f32(const float* sigma, const float* origin, const float* gt_pts,
                          const float* tindex, float* ce, float* lse, float* valid, int F, int R,
                          int Z, int Y, int X, int K, float step, void* stream);
 int vidar_ray_ce_bwd_f32(const float* sigma, const float* origin, const float* gt_pts,
                          const float* tindex, const float* lse, const float* grad_ce,
                          float* grad_sigma, int F, int R, int Z, int Y, int X, int K, float step,
-                         void* stream);
+                         void* workspace, size_t workspace_bytes, void* stream);
 int vidar_ray_gumbel_fwd_f32(const float* sigma, const float* origin, const float* pts,
                              const float* tindex, const float* noise /*[R,K]*/, float* dist,
                              float* aux /*[R,3]*/, int F, int R, int Z, int Y, int X, int K,
@@ -304,7 +317,7 @@ int vidar_ray_gumbel_fwd_f32(const float* sigma, const float* origin, const floa
 int vidar_ray_gumbel_bwd_f32(const float* sigma, const float* origin, const float* pts,
                              const float* tindex, const float* aux, const float* grad_dist,
                              float* grad_sigma, int F, int R, int Z, int Y, int X, int K, float step,
-                             void* stream);
+                             void* workspace, size_t workspace_bytes, void* stream);
 int vidar_ray_argmax_f32(const float* sigma, const float* origin, const float* pts,
                          const float* tindex, float* pred_dist, float* gt_dist, int F, int R, int Z,
                          int Y, int X, int K, float step, void* stream);

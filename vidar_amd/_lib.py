@@ -46,6 +46,19 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def workspace(nbytes_fn, *dims, like):
+    """Caller-owned device scratch for an op: `nbytes_fn(*dims)` bytes from torch's caching allocator on `like`'s
+    device (so it lives on the op's device and stream and is counted by torch's memory statistics).
+    -> (tensor or None, pointer, size_t): keep the tensor alive until the call has been enqueued."""
+    import torch
+    nbytes_fn.restype = ctypes.c_size_t
+    n = int(nbytes_fn(*dims))
+    if n == 0:
+        return None, None, ctypes.c_size_t(0)
+    ws = torch.empty(n, dtype=torch.uint8, device=like.device)
+    return ws, ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(n)
+
+
 def stream_of(t):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)

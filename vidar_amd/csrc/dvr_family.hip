@@ -226,11 +226,14 @@ __global__ __launch_bounds__(256) void dvxlr_scatter_kernel(
     const float* __restrict__ em, const float* __restrict__ indices,
     const float* __restrict__ tindex, const float* __restrict__ indicator,
     const float* __restrict__ grad_ray_pred, float* __restrict__ grad_sigma,
-    float* __restrict__ grad_regul, int M, int L, Vol g) {
+    float* __restrict__ grad_regul, int M, int L, Vol g, int ncopies, size_t copy_stride) {
   const int n = blockIdx.y;
   const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
   const int c = blockIdx.x * (256 / kWave) + wave;
   if (c >= M) return;
+  // rays of one frame share their first voxels (the sensor origin): workgroup i adds into private copy i mod n
+  grad_sigma += (size_t)(blockIdx.x % ncopies) * copy_stride;
+  if (V2) grad_regul += (size_t)(blockIdx.x % ncopies) * copy_stride;
   const float t = tindex[(size_t)n * M + c];
   if (t < 0.f || t != t) return;
   const long ti = (long)t;
@@ -258,6 +261,16 @@ __global__ __launch_bounds__(256) void dvxlr_scatter_kernel(
     if (v != 0.f) unsafeAtomicAdd(gs + o, v);
     if (V2 && rv != 0.f) unsafeAtomicAdd(gr + o, rv);
   }
+}
+
+constexpr int kScatterCopies = 8;
+__global__ __launch_bounds__(256) void dvxlr_sum_copies_kernel(const float* __restrict__ copies, float* __restrict__ out,
+                                                               size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = copies[i];
+  for (int c = 1; c < kScatterCopies; ++c) a += copies[(size_t)c * n + i];
+  out[i] = a;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -451,20 +464,31 @@ int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float
                              (hipStream_t)stream);
 }
 
+size_t vidar_dvxlr_get_grad_sigma_workspace_bytes(int N, int T, int Z, int Y, int X) {
+  if (bad_dims(N, 0, T, Z, Y, X)) return 0;
+  return sizeof(float) * (size_t)N * T * Z * Y * X * kScatterCopies * 2;   // _v2: two volumes; v1 uses half
+}
+
 int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult, const float* indices,
                                    const float* tindex, float* grad_sigma, int N, int M, int L, int T,
-                                   int Z, int Y, int X, void* stream) {
+                                   int Z, int Y, int X, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
   VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || L < 0) return VIDAR_ERR_BAD_ARG;
-  hipError_t e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * (size_t)N * T * Z * Y * X,
-                                (hipStream_t)stream);
+  const size_t n = (size_t)N * T * Z * Y * X;
+  const bool copies = workspace != nullptr && workspace_bytes >= sizeof(float) * n * kScatterCopies;
+  float* acc = copies ? (float*)workspace : grad_sigma;
+  hipStream_t s_ = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * n * (copies ? kScatterCopies : 1), s_);
   if (e != hipSuccess) return (int)e;
-  if (N == 0 || M == 0 || L == 0) return 0;
+  if (N == 0 || M == 0 || L == 0) return copies ? (int)hipMemsetAsync(grad_sigma, 0, sizeof(float) * n, s_) : 0;
   Vol g{T, T, Z, Y, X};
   dim3 grid((M + 3) / 4, N);
-  hipLaunchKernelGGL(dvxlr_scatter_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
-                     elementwise_mult, indices, tindex, (const float*)nullptr, (const float*)nullptr,
-                     grad_sigma, (float*)nullptr, M, L, g);
+  hipLaunchKernelGGL(dvxlr_scatter_kernel<false>, grid, dim3(256), 0, s_, elementwise_mult, indices, tindex,
+                     (const float*)nullptr, (const float*)nullptr, acc, (float*)nullptr, M, L, g,
+                     copies ? kScatterCopies : 1, n);
+  if (copies)
+    hipLaunchKernelGGL(dvxlr_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s_, acc, grad_sigma, n);
   return vidar_last_error();
 }
 
@@ -472,20 +496,37 @@ int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* 
                                     const float* tindex, const float* indicator,
                                     const float* grad_ray_pred, float* grad_sigma,
                                     float* grad_sigma_regul, int N, int M, int L, int T, int Z, int Y,
-                                    int X, void* stream) {
+                                    int X, void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || L < 0) return VIDAR_ERR_BAD_ARG;
-  const size_t bytes = sizeof(float) * (size_t)N * T * Z * Y * X;
-  hipError_t e = hipMemsetAsync(grad_sigma, 0, bytes, (hipStream_t)stream);
+  const size_t n = (size_t)N * T * Z * Y * X;
+  const bool copies = workspace != nullptr && workspace_bytes >= vidar_dvxlr_get_grad_sigma_workspace_bytes(N, T, Z, Y, X);
+  float* acc = copies ? (float*)workspace : grad_sigma;
+  float* acc2 = copies ? (float*)workspace + n * kScatterCopies : grad_sigma_regul;
+  hipStream_t s_ = (hipStream_t)stream;
+  hipError_t e;
+  if (copies) {
+    e = hipMemsetAsync(acc, 0, sizeof(float) * n * kScatterCopies * 2, s_);
+  } else {
+    e = hipMemsetAsync(acc, 0, sizeof(float) * n, s_);
+    if (e == hipSuccess) e = hipMemsetAsync(acc2, 0, sizeof(float) * n, s_);
+  }
   if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(grad_sigma_regul, 0, bytes, (hipStream_t)stream);
-  if (e != hipSuccess) return (int)e;
-  if (N == 0 || M == 0 || L == 0) return 0;
+  if (N == 0 || M == 0 || L == 0) {
+    if (!copies) return 0;
+    e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * n, s_);
+    if (e == hipSuccess) e = hipMemsetAsync(grad_sigma_regul, 0, sizeof(float) * n, s_);
+    return (int)e;
+  }
   Vol g{T, T, Z, Y, X};
   dim3 grid((M + 3) / 4, N);
-  hipLaunchKernelGGL(dvxlr_scatter_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
-                     elementwise_mult, indices, tindex, indicator, grad_ray_pred, grad_sigma,
-                     grad_sigma_regul, M, L, g);
+  hipLaunchKernelGGL(dvxlr_scatter_kernel<true>, grid, dim3(256), 0, s_, elementwise_mult, indices, tindex, indicator,
+                     grad_ray_pred, acc, acc2, M, L, g, copies ? kScatterCopies : 1, n);
+  if (copies) {
+    const dim3 rg((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(dvxlr_sum_copies_kernel, rg, dim3(256), 0, s_, acc, grad_sigma, n);
+    hipLaunchKernelGGL(dvxlr_sum_copies_kernel, rg, dim3(256), 0, s_, acc2, grad_sigma_regul, n);
+  }
   return vidar_last_error();
 }
 

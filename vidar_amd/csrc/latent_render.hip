@@ -33,13 +33,14 @@ constexpr int kCellsPerBlock = kThreads / 64;
 
 // Every ray starts at the BEV centre, so the first waypoints of all H*W rays scatter onto the same few cells and the
 // atomics on those addresses serialise: the backward kernels add into kCopies private copies of the gradient maps
-// (workgroup i -> copy i mod n; neighbouring workgroups = neighbouring cells = nearly the same ray) and a small kernel
-// sums the copies -- n times fewer atomics per hot address for the same total number.  Measured on MI355X
+// (workgroup i -> copy i mod n; neighbouring workgroups = neighbouring cells = nearly the same ray), kept in the
+// CALLER's workspace (vidar_latent_render_bwd_workspace_bytes; without one they add straight into the outputs), and a
+// small kernel sums the copies -- n times fewer atomics per hot address for the same total number.  Measured on MI355X
 // (profiles/r04_staged_variants_kernel_times.log): lr_prob_bwd 0.66 -> 0.48 ms, lr_gather_bwd 1.32 -> 1.08 ms with 8
 // copies, memset and sum included: the kernels were serialised on the hot addresses, not bound by the atomic rate.
 constexpr int kCopies = 8;
 // which private copy this workgroup adds into, as an offset in maps of [bs, Q, 16] (0 when the variant is off)
-__device__ __forceinline__ size_t copy_of_block() { return (size_t)(blockIdx.x % kCopies) * gridDim.y; }
+__device__ __forceinline__ size_t copy_of_block(int ncopies) { return (size_t)(blockIdx.x % ncopies) * gridDim.y; }
 
 struct Geo {
   int H, W, G;
@@ -197,13 +198,13 @@ __global__ __launch_bounds__(kThreads) void lr_prob_fwd_kernel(const float* __re
 __global__ __launch_bounds__(kThreads) void lr_prob_bwd_kernel(const float* __restrict__ occ,
                                                                const float* __restrict__ grad_prob,
                                                                float* __restrict__ grad_occ, int Q,
-                                                               Geo g) {
+                                                               Geo g, int ncopies) {
   const int b = blockIdx.y;
   const int q = blockIdx.x * kCellsPerBlock + threadIdx.x / 64;
   if (q >= Q) return;
   const int lane = threadIdx.x & 63, z = lane & 15, ks = lane >> 4;
   const float* map = occ + (size_t)b * Q * kZ;
-  float* gmap = grad_occ + (copy_of_block() + b) * Q * kZ;
+  float* gmap = grad_occ + (copy_of_block(ncopies) + b) * Q * kZ;
   const Cell c = make_cell(q, g);
   // pass 1: the transmittance product
   float pr = 1.f;
@@ -273,15 +274,15 @@ __global__ __launch_bounds__(kThreads) void lr_gather_fwd_kernel(const float* __
 __global__ __launch_bounds__(kThreads) void lr_gather_bwd_kernel(
     const float* __restrict__ prob, const float* __restrict__ a, const float* __restrict__ feat,
     const float* __restrict__ msum, const float* __restrict__ grad_feat,
-    float* __restrict__ grad_prob, float* __restrict__ grad_a, int Q, Geo g) {
+    float* __restrict__ grad_prob, float* __restrict__ grad_a, int Q, Geo g, int ncopies) {
   const int b = blockIdx.y;
   const int q = blockIdx.x * kCellsPerBlock + threadIdx.x / 64;
   if (q >= Q) return;
   const int lane = threadIdx.x & 63, z = lane & 15, ks = lane >> 4;
   const float* pm = prob + (size_t)b * Q * kZ;
   const float* am = a + (size_t)b * Q * kZ;
-  float* gpm = grad_prob + (copy_of_block() + b) * Q * kZ;
-  float* gam = grad_a + (copy_of_block() + b) * Q * kZ;
+  float* gpm = grad_prob + (copy_of_block(ncopies) + b) * Q * kZ;
+  float* gam = grad_a + (copy_of_block(ncopies) + b) * Q * kZ;
   const Cell c = make_cell(q, g);
   const size_t o = ((size_t)b * Q + q) * kZ + z;
   const float f = feat[o];
@@ -310,19 +311,6 @@ __global__ __launch_bounds__(256) void lr_sum_copies_kernel(const float4* __rest
   }
   out[i] = a;
 }
-// device scratch for the private copies: grown on demand, kept for the life of the process (experiment only)
-float* g_lr_scratch = nullptr;
-size_t g_lr_scratch_floats = 0;
-inline float* lr_scratch(size_t floats) {
-  if (floats > g_lr_scratch_floats) {
-    if (g_lr_scratch) (void)hipFree(g_lr_scratch);
-    g_lr_scratch = nullptr; g_lr_scratch_floats = 0;
-    if (hipMalloc(&g_lr_scratch, floats * sizeof(float)) != hipSuccess) return nullptr;
-    g_lr_scratch_floats = floats;
-  }
-  return g_lr_scratch;
-}
-
 inline bool lr_bad(int bs, int H, int W, int Z, int G, int act) {
   return bs < 0 || H <= 0 || W <= 0 || Z != kZ || G <= 0 || (act != 0 && act != 1);
 }
@@ -331,6 +319,11 @@ inline dim3 lr_grid(int bs, int Q) { return dim3((Q + kCellsPerBlock - 1) / kCel
 }  // namespace
 
 extern "C" {
+
+size_t vidar_latent_render_bwd_workspace_bytes(int bs, int H, int W, int Z) {
+  if (bs <= 0 || H <= 0 || W <= 0 || Z <= 0) return 0;
+  return sizeof(float) * 2 * (size_t)bs * H * W * Z * kCopies;     // gather_bwd: two maps; prob_bwd uses half
+}
 
 int vidar_latent_render_prob_fwd_f32(const float* occ, float* path_prob, int bs, int H, int W, int Z,
                                      int grid_num, float step, int act, void* stream) {
@@ -345,20 +338,23 @@ int vidar_latent_render_prob_fwd_f32(const float* occ, float* path_prob, int bs,
 
 int vidar_latent_render_prob_bwd_f32(const float* occ, const float* grad_path_prob, float* grad_occ,
                                      int bs, int H, int W, int Z, int grid_num, float step, int act,
-                                     void* stream) {
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
   if (lr_bad(bs, H, W, Z, grid_num, act)) return VIDAR_ERR_BAD_ARG;
   if (bs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   Geo g{H, W, grid_num, step, act, 0.f};
   const size_t n = (size_t)bs * H * W * Z;
-  float* sc = lr_scratch(2 * n * kCopies);
-  if (!sc) return (int)hipErrorOutOfMemory;
-  hipError_t e = hipMemsetAsync(sc, 0, sizeof(float) * n * kCopies, s);
+  const bool copies = workspace != nullptr && workspace_bytes >= sizeof(float) * n * kCopies &&
+                      (((uintptr_t)workspace | (uintptr_t)grad_occ) & 15u) == 0;
+  float* acc = copies ? (float*)workspace : grad_occ;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * n * (copies ? kCopies : 1), s);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(lr_prob_bwd_kernel, lr_grid(bs, H * W), dim3(kThreads), 0, s, occ, grad_path_prob, sc, H * W, g);
-  hipLaunchKernelGGL(lr_sum_copies_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
-                     (const float4*)sc, (float4*)grad_occ, n / 4);
+  hipLaunchKernelGGL(lr_prob_bwd_kernel, lr_grid(bs, H * W), dim3(kThreads), 0, s, occ, grad_path_prob, acc, H * W, g,
+                     copies ? kCopies : 1);
+  if (copies)
+    hipLaunchKernelGGL(lr_sum_copies_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
+                       (const float4*)acc, (float4*)grad_occ, n / 4);
   return vidar_last_error();
 }
 
@@ -378,24 +374,32 @@ int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora
                                        const float* msum, const float* grad_feat,
                                        float* grad_path_prob, float* grad_lora_a, int bs, int H,
                                        int W, int Z, int grid_num, float step, float eps,
-                                       void* stream) {
+                                       void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
   if (lr_bad(bs, H, W, Z, grid_num, 0)) return VIDAR_ERR_BAD_ARG;
   if (bs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   Geo g{H, W, grid_num, step, 0, eps};
   const size_t n = (size_t)bs * H * W * Z;
-  float* sc = lr_scratch(2 * n * kCopies);
-  if (!sc) return (int)hipErrorOutOfMemory;
-  hipError_t e = hipMemsetAsync(sc, 0, sizeof(float) * 2 * n * kCopies, s);
+  const bool copies = workspace != nullptr && workspace_bytes >= vidar_latent_render_bwd_workspace_bytes(bs, H, W, Z) &&
+                      (((uintptr_t)workspace | (uintptr_t)grad_path_prob | (uintptr_t)grad_lora_a) & 15u) == 0;
+  float* sp = copies ? (float*)workspace : grad_path_prob;
+  float* sa = copies ? (float*)workspace + n * kCopies : grad_lora_a;
+  hipError_t e;
+  if (copies) {
+    e = hipMemsetAsync(sp, 0, sizeof(float) * 2 * n * kCopies, s);
+  } else {
+    e = hipMemsetAsync(sp, 0, sizeof(float) * n, s);
+    if (e == hipSuccess) e = hipMemsetAsync(sa, 0, sizeof(float) * n, s);
+  }
   if (e != hipSuccess) return (int)e;
-  float* sp = sc;
-  float* sa = sc + n * kCopies;
   hipLaunchKernelGGL(lr_gather_bwd_kernel, lr_grid(bs, H * W), dim3(kThreads), 0, s, path_prob, lora_a, feat, msum,
-                     grad_feat, sp, sa, H * W, g);
-  const dim3 rg((unsigned)((n / 4 + 255) / 256));
-  hipLaunchKernelGGL(lr_sum_copies_kernel, rg, dim3(256), 0, s, (const float4*)sp, (float4*)grad_path_prob, n / 4);
-  hipLaunchKernelGGL(lr_sum_copies_kernel, rg, dim3(256), 0, s, (const float4*)sa, (float4*)grad_lora_a, n / 4);
+                     grad_feat, sp, sa, H * W, g, copies ? kCopies : 1);
+  if (copies) {
+    const dim3 rg((unsigned)((n / 4 + 255) / 256));
+    hipLaunchKernelGGL(lr_sum_copies_kernel, rg, dim3(256), 0, s, (const float4*)sp, (float4*)grad_path_prob, n / 4);
+    hipLaunchKernelGGL(lr_sum_copies_kernel, rg, dim3(256), 0, s, (const float4*)sa, (float4*)grad_lora_a, n / 4);
+  }
   return vidar_last_error();
 }
 

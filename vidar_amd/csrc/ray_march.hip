@@ -134,7 +134,8 @@ constexpr float kNegInf = -__builtin_inff();
 // Every ray of a frame starts at the sensor origin, so the first waypoints of all rays of a frame scatter onto the same
 // 8-27 voxels (210 000 rays x ~3 waypoints x 8 corners onto ~190 addresses in one ray_ce_bwd launch) and the atomics on
 // those addresses serialise: the backward kernels add into kRayCopies private copies of the gradient volume
-// (workgroup i -> copy i mod n) and a small kernel sums them.  Measured on MI355X
+// (workgroup i -> copy i mod n) kept in the CALLER's workspace (vidar_ray_bwd_workspace_bytes; without one they add
+// straight into grad_sigma) and a small kernel sums them.  Measured on MI355X
 // (profiles/r04_staged_variants_kernel_times.log): ray_ce_bwd 0.69 -> 0.41 ms, ray_gumbel_bwd 0.41 -> 0.29 ms with 8
 // copies, memset and sum included.  (Leaving the 512-waypoint loops after the run of live waypoints -- the waypoints
 // inside the volume are ONE run of consecutive k, tests/test_ray_early_exit_cpu.py -- was measured too: no change,
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void ray_ce_bwd_kernel(
     const float* __restrict__ sigma, const float* __restrict__ origin, const float* __restrict__ gt,
     const float* __restrict__ tindex, const float* __restrict__ lse_in,
     const float* __restrict__ grad_ce, float* __restrict__ grad_sigma, int R, VolDims v,
-    float step) {
+    float step, int ncopies) {
   const int r = blockIdx.x * kRaysPerBlock + threadIdx.x / kWave;
   if (r >= R) return;
   const int lane = threadIdx.x % kWave;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void ray_ce_bwd_kernel(
   if (ray.f < 0 || t0.masked) return;
   const size_t slice = (size_t)ray.f * v.Z * v.Y * v.X;
   const float* vol = sigma + slice;
-  float* gvol = grad_sigma + (size_t)(blockIdx.x % kRayCopies) * v.F * v.Z * v.Y * v.X + slice;
+  float* gvol = grad_sigma + (size_t)(blockIdx.x % ncopies) * v.F * v.Z * v.Y * v.X + slice;
   const float lse = lse_in[r];
   if (lane == 0) tri_scatter(gvol, t0, g * (expf(tri_load(vol, t0) - lse) - 1.f));
   const int cx = lane & 1;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
     const float* __restrict__ sigma, const float* __restrict__ origin, const float* __restrict__ pts,
     const float* __restrict__ tindex, const float* __restrict__ aux,
     const float* __restrict__ grad_dist, float* __restrict__ grad_sigma, int R, VolDims v,
-    float step) {
+    float step, int ncopies) {
   const int r = blockIdx.x * kRaysPerBlock + threadIdx.x / kWave;
   if (r >= R) return;
   const int lane = threadIdx.x % kWave;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void ray_gumbel_bwd_kernel(
   if (ray.f < 0) return;
   const size_t slice = (size_t)ray.f * v.Z * v.Y * v.X;
   const float* vol = sigma + slice;
-  float* gvol = grad_sigma + (size_t)(blockIdx.x % kRayCopies) * v.F * v.Z * v.Y * v.X + slice;
+  float* gvol = grad_sigma + (size_t)(blockIdx.x % ncopies) * v.F * v.Z * v.Y * v.X + slice;
   const float pd = aux[(size_t)r * 3 + 0], pn = aux[(size_t)r * 3 + 1], lse = aux[(size_t)r * 3 + 2];
   const int cx = lane & 1;
   for (int j = 0; j < 2 * kPerLane; ++j) {             // 32 waypoints per pass, a lane pair per waypoint
@@ -356,20 +357,14 @@ __global__ __launch_bounds__(256) void ray_sum_copies_kernel(const float* __rest
   for (int c = 1; c < kRayCopies; ++c) a += copies[(size_t)c * n + i];
   out[i] = a;
 }
-float* g_ray_scratch = nullptr;            // grown on demand, kept for the life of the process (experiment only)
-size_t g_ray_scratch_floats = 0;
-inline float* ray_scratch(size_t floats) {
-  if (floats > g_ray_scratch_floats) {
-    if (g_ray_scratch) (void)hipFree(g_ray_scratch);
-    g_ray_scratch = nullptr; g_ray_scratch_floats = 0;
-    if (hipMalloc(&g_ray_scratch, floats * sizeof(float)) != hipSuccess) return nullptr;
-    g_ray_scratch_floats = floats;
-  }
-  return g_ray_scratch;
-}
 }  // namespace
 
 extern "C" {
+
+size_t vidar_ray_bwd_workspace_bytes(int F, int Z, int Y, int X) {
+  if (F <= 0 || Z <= 0 || Y <= 0 || X <= 0) return 0;
+  return sizeof(float) * (size_t)F * Z * Y * X * kRayCopies;
+}
 
 int vidar_ray_ce_fwd_f32(const float* sigma, const float* origin, const float* gt_pts,
                          const float* tindex, float* ce, float* lse, float* valid, int F, int R,
@@ -386,22 +381,21 @@ int vidar_ray_ce_fwd_f32(const float* sigma, const float* origin, const float* g
 int vidar_ray_ce_bwd_f32(const float* sigma, const float* origin, const float* gt_pts,
                          const float* tindex, const float* lse, const float* grad_ce,
                          float* grad_sigma, int F, int R, int Z, int Y, int X, int K, float step,
-                         void* stream) {
+                         void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
   if (rm_bad(F, R, Z, Y, X, K)) return VIDAR_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * (size_t)F * Z * Y * X, s);
-  if (e != hipSuccess) return (int)e;
-  if (R == 0) return 0;
-  VolDims v{F, Z, Y, X};
   const size_t n = (size_t)F * Z * Y * X;
-  float* sc = ray_scratch(n * kRayCopies);
-  if (!sc) return (int)hipErrorOutOfMemory;
-  e = hipMemsetAsync(sc, 0, sizeof(float) * n * kRayCopies, s);
+  const bool copies = workspace != nullptr && workspace_bytes >= vidar_ray_bwd_workspace_bytes(F, Z, Y, X);
+  float* acc = copies ? (float*)workspace : grad_sigma;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * n * (copies ? kRayCopies : 1), s);
   if (e != hipSuccess) return (int)e;
+  if (R == 0) return copies ? (int)hipMemsetAsync(grad_sigma, 0, sizeof(float) * n, s) : 0;
+  VolDims v{F, Z, Y, X};
   hipLaunchKernelGGL(ray_ce_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, gt_pts, tindex, lse, grad_ce,
-                     sc, R, v, step);
-  hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc, grad_sigma, n);
+                     acc, R, v, step, copies ? kRayCopies : 1);
+  if (copies)
+    hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc, grad_sigma, n);
   return vidar_last_error();
 }
 
@@ -420,22 +414,21 @@ int vidar_ray_gumbel_fwd_f32(const float* sigma, const float* origin, const floa
 int vidar_ray_gumbel_bwd_f32(const float* sigma, const float* origin, const float* pts,
                              const float* tindex, const float* aux, const float* grad_dist,
                              float* grad_sigma, int F, int R, int Z, int Y, int X, int K, float step,
-                             void* stream) {
+                             void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
   if (rm_bad(F, R, Z, Y, X, K)) return VIDAR_ERR_BAD_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_sigma, 0, sizeof(float) * (size_t)F * Z * Y * X, s);
-  if (e != hipSuccess) return (int)e;
-  if (R == 0) return 0;
-  VolDims v{F, Z, Y, X};
   const size_t n = (size_t)F * Z * Y * X;
-  float* sc = ray_scratch(n * kRayCopies);
-  if (!sc) return (int)hipErrorOutOfMemory;
-  e = hipMemsetAsync(sc, 0, sizeof(float) * n * kRayCopies, s);
+  const bool copies = workspace != nullptr && workspace_bytes >= vidar_ray_bwd_workspace_bytes(F, Z, Y, X);
+  float* acc = copies ? (float*)workspace : grad_sigma;
+  hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * n * (copies ? kRayCopies : 1), s);
   if (e != hipSuccess) return (int)e;
+  if (R == 0) return copies ? (int)hipMemsetAsync(grad_sigma, 0, sizeof(float) * n, s) : 0;
+  VolDims v{F, Z, Y, X};
   hipLaunchKernelGGL(ray_gumbel_bwd_kernel, rm_grid(R), dim3(kThreads), 0, s, sigma, origin, pts, tindex, aux,
-                     grad_dist, sc, R, v, step);
-  hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sc, grad_sigma, n);
+                     grad_dist, acc, R, v, step, copies ? kRayCopies : 1);
+  if (copies)
+    hipLaunchKernelGGL(ray_sum_copies_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acc, grad_sigma, n);
   return vidar_last_error();
 }
 

@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from ..._lib import lib, check, ptr, stream_of, TIMER
+from ..._lib import lib, check, ptr, stream_of, workspace, TIMER
 
 K_SAMPLES = 512
 
@@ -45,10 +45,11 @@ class _RayCE(Function):
         step, K = ctx.cfg
         F_, R, Z, Y, X = _dims(sigma, gt)
         g = torch.empty_like(sigma)
+        ws, wsp, wsn = workspace(lib().vidar_ray_bwd_workspace_bytes, F_, Z, Y, X, like=sigma)
         with TIMER.span("ray_ce_bwd", 4 * (2 * sigma.numel() + R * 6)):
           check(lib().vidar_ray_ce_bwd_f32(ptr(sigma), ptr(origin), ptr(gt), ptr(tindex), ptr(lse),
                                          ptr(_f(grad_ce)), ptr(g), F_, R, Z, Y, X, K,
-                                         ctypes.c_float(step), stream_of(sigma)), "ray_ce_bwd")
+                                         ctypes.c_float(step), wsp, wsn, stream_of(sigma)), "ray_ce_bwd")
         return g, None, None, None, None, None
 
 
@@ -75,10 +76,11 @@ class _RayGumbel(Function):
         step, K = ctx.cfg
         F_, R, Z, Y, X = _dims(sigma, pts)
         g = torch.empty_like(sigma)
+        ws, wsp, wsn = workspace(lib().vidar_ray_bwd_workspace_bytes, F_, Z, Y, X, like=sigma)
         with TIMER.span("ray_gumbel_bwd", 4 * (2 * sigma.numel() + R * 8)):
           check(lib().vidar_ray_gumbel_bwd_f32(ptr(sigma), ptr(origin), ptr(pts), ptr(tindex), ptr(aux),
                                              ptr(_f(grad_dist)), ptr(g), F_, R, Z, Y, X, K,
-                                             ctypes.c_float(step), stream_of(sigma)), "ray_gumbel_bwd")
+                                             ctypes.c_float(step), wsp, wsn, stream_of(sigma)), "ray_gumbel_bwd")
         return g, None, None, None, None, None, None
 
 

@@ -15,7 +15,7 @@ from torch.autograd.function import once_differentiable
 
 from ...bricks import Linear
 from ...registry import ATTENTION
-from ...._lib import lib, check, ptr, stream_of, TIMER
+from ...._lib import lib, check, ptr, stream_of, workspace, TIMER
 
 _ACT = {"sigmoid": 0, "exp": 1}
 
@@ -47,10 +47,11 @@ class _PathProb(Function):
         grid_num, step, act = ctx.cfg
         bs, H, W, Z = occ.shape
         g = torch.empty_like(occ)
+        ws, wsp, wsn = workspace(lib().vidar_latent_render_bwd_workspace_bytes, bs, H, W, Z, like=occ)
         with TIMER.span("lr_prob_bwd", 4 * occ.numel() * 3):
           check(lib().vidar_latent_render_prob_bwd_f32(ptr(occ), ptr(grad_prob.float().contiguous()),
                                                      ptr(g), bs, H, W, Z, grid_num,
-                                                     ctypes.c_float(step), act, stream_of(occ)),
+                                                     ctypes.c_float(step), act, wsp, wsn, stream_of(occ)),
               "latent_render_prob_bwd")
         return g, None, None, None
 
@@ -78,12 +79,13 @@ class _RayGather(Function):
         grid_num, step, eps = ctx.cfg
         bs, H, W, Z = prob.shape
         gp = torch.empty_like(prob); ga = torch.empty_like(a)
+        ws, wsp, wsn = workspace(lib().vidar_latent_render_bwd_workspace_bytes, bs, H, W, Z, like=prob)
         with TIMER.span("lr_gather_bwd", 4 * prob.numel() * 7):
           check(lib().vidar_latent_render_gather_bwd_f32(ptr(prob), ptr(a), ptr(feat), ptr(msum),
                                                        ptr(grad_feat.float().contiguous()), ptr(gp),
                                                        ptr(ga), bs, H, W, Z, grid_num,
                                                        ctypes.c_float(step), ctypes.c_float(eps),
-                                                       stream_of(prob)), "latent_render_gather_bwd")
+                                                       wsp, wsn, stream_of(prob)), "latent_render_gather_bwd")
         return gp, ga, None, None, None
 
 

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 
-from .._lib import lib, check, ptr, stream_of
+from .._lib import lib, check, ptr, stream_of, workspace
 from ._common import check_input, ray_dims
 
 MAX_D = 1026  # dvxlr.cu:10
@@ -32,8 +32,9 @@ def get_grad_sigma(elementwise_mult, indices, tindex, sigma_shape):
     N, T, Z, Y, X = sigma_shape.shape
     M, L = elementwise_mult.shape[1], elementwise_mult.shape[2]
     grad = torch.empty((N, T, Z, Y, X), device=elementwise_mult.device)
+    ws, wsp, wsn = workspace(lib().vidar_dvxlr_get_grad_sigma_workspace_bytes, N, T, Z, Y, X, like=grad)
     check(lib().vidar_dvxlr_get_grad_sigma_f32(ptr(elementwise_mult), ptr(indices), ptr(tindex),
-                                               ptr(grad), N, M, L, T, Z, Y, X,
+                                               ptr(grad), N, M, L, T, Z, Y, X, wsp, wsn,
                                                stream_of(grad)), "dvxlr.get_grad_sigma")
     return [grad]
 

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from .._lib import lib, check, ptr, stream_of
+from .._lib import lib, check, ptr, stream_of, workspace
 from ._common import check_input, ray_dims
 
 MAX_D = 1026
@@ -37,8 +37,9 @@ def get_grad_sigma_v2(elementwise_mult, indices, tindex, sigma_shape, indicator,
     M, L = elementwise_mult.shape[1], elementwise_mult.shape[2]
     dev = elementwise_mult.device
     g = torch.empty((N, T, Z, Y, X), device=dev); g2 = torch.empty((N, T, Z, Y, X), device=dev)
+    ws, wsp, wsn = workspace(lib().vidar_dvxlr_get_grad_sigma_workspace_bytes, N, T, Z, Y, X, like=g)
     check(lib().vidar_dvxlr2_get_grad_sigma_f32(ptr(elementwise_mult), ptr(indices), ptr(tindex),
                                                 ptr(indicator), ptr(grad_ray_pred), ptr(g), ptr(g2),
-                                                N, M, L, T, Z, Y, X, stream_of(g)),
+                                                N, M, L, T, Z, Y, X, wsp, wsn, stream_of(g)),
           "dvxlr_v2.get_grad_sigma_v2")
     return [g, g2]
