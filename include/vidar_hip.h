@@ -79,8 +79,8 @@ int vidar_dvxlr_max_d(void); /* 1026, third_lib/dvxlr/dvxlr.cu:10 */
 int vidar_dvr_set_sort_min_waves(int min_waves);
 /* which traversal the dvr / dvxlr march launches use: -1 (default) = step-parallel kernels (independent per-axis
  * tMax chains -- dvr.cu:232-251, dvxlr.cu:334-353 advance tMaxX only on X steps -- merged by exact comparisons,
- * lane-per-step integration; csrc/dvr_par.h) where they are the faster form (dvr.render and the one-launch
- * dvxlr.render / render_v2 at every size, dvr.render_forward up to 24 576 rays), lane-per-ray kernels otherwise;
+ * lane-per-step integration; csrc/dvr_par.h) where they are the faster form (dvr.render at every size, the one-launch
+ * dvxlr.render / render_v2 up to 98 304 rays, dvr.render_forward up to 24 576 rays), lane-per-ray kernels otherwise;
  * 0 = always lane-per-ray, 1 = always step-parallel.  Results do not depend on it: index lists and gt_dist are
  * bit-identical (tests/test_dvr_gpu.py runs every case under both).  Returns the previous value. */
 int vidar_dvr_set_traversal(int mode);

@@ -95,9 +95,10 @@ inline bool step_parallel(int N, int M, const Vol& g, long auto_max_rays) {
   return (long)N * M <= auto_max_rays;
 }
 // measured crossovers (profiles/r05_kbench_dvr_traversal.log): render_forward stores nothing, so its step-parallel form
-// only wins while the lane-per-ray launch is far from filling the chip; dvr.render (coalesced atomics) and the
-// one-launch dvxlr.render (padding streamed next to the march) win at every measured size
-constexpr long kParAutoForward = 24576, kParAutoRender = 1L << 40, kParAutoDvxlr = 1L << 40;
+// only wins while the lane-per-ray launch is far from filling the chip; dvr.render (coalesced lane-per-step atomics)
+// wins at every measured size; the one-launch dvxlr.render / render_v2 (padding streamed next to the march) win up to
+// ~90 000 rays and tie with the three-launch lane-per-ray form above (box-to-box spread larger than the difference)
+constexpr long kParAutoForward = 24576, kParAutoRender = 1L << 40, kParAutoDvxlr = 98304;
 template <int KIND>
 inline void launch_par(const float* sigma, const float* sigma_regul, const float* origin, const float* points,
                        const float* tindex, float* pred_dist, float* gt_dist, float* dd_dsigma, float* indices,
