@@ -64,19 +64,22 @@ def parse():
     ap.add_argument("--cpu-baseline-step", action="store_true",
                     help="also time the oracle port of the WHOLE step on a bounded sample (BEV 50x50; round-2 leg)")
     ap.add_argument("--extra-configs",
-                    default="vidar_1_8_nusc_3future,mem_efficient_vidar_1_8_nusc_3future,vidar_OpenScene_mini_full_3future,"
-                            "vidar_1_8_nusc_1future@1:bf16x3,vidar_1_8_nusc_3future@1:bf16x3,"
-                            "vidar_full_nusc_1future@2,vidar_full_nusc_1future@4",
-                    help="comma-separated `config[@samples_per_gpu][:gemm]` entries timed after the main one in the same "
+                    default="vidar_1_8_nusc_3future!,vidar_1_8_nusc_1future@1:bf16x3!,"
+                            "mem_efficient_vidar_1_8_nusc_3future,vidar_OpenScene_mini_full_3future,"
+                            "vidar_1_8_nusc_3future@1:bf16x3,"
+                            "vidar_full_nusc_1future@2,vidar_full_nusc_1future@4,vidar_full_nusc_1future@8",
+                    help="comma-separated `config[@samples_per_gpu][:gemm][!]` entries timed after the main one in the same "
                          "run (short records under `configs`, each with its peak device memory): BASELINE.json's other "
                          "named configs -- the north star's target sentence names vidar_1_8_nusc_3future (and the "
                          "reference's memory-efficient variant of it, README.md:143-148); OpenScene = 8 cameras; "
                          ":bf16x3 = the split-bf16 MFMA GEMM path (a labelled second record, the headline stays fp32); "
-                         "@2/@4 = per-GPU batch sweep of config c3 (\"per-GPU batch sized to 288 GB\")")
+                         "@2/@4/@8 = per-GPU batch sweep of config c3 (\"per-GPU batch sized to 288 GB\": 8 samples "
+                         "are ~260 GB); a trailing ! = timed with the headline's --steps / --warmup instead of "
+                         "--extra-steps / --extra-warmup (the north star's target config and the bf16x3 record)")
     ap.add_argument("--gemm", choices=["lib", "auto", "f32", "bf16x3"], default=None,
                     help="what the Linear / 1x1-convolution products of the main record run on (default: vidar_amd.gemm."
                          "mode(), i.e. $VIDAR_GEMM or the package default); extra configs take it as `name@spg:gemm`")
-    ap.add_argument("--extra-budget-s", type=float, default=240.0,
+    ap.add_argument("--extra-budget-s", type=float, default=270.0,
                     help="wall-clock budget of the extra configs together: entries that would start after it are recorded "
                          "as skipped (the contract line must appear within minutes)")
     ap.add_argument("--extra-steps", type=int, default=5)
@@ -94,6 +97,26 @@ def parse():
                     help="leave the library GEMMs on their default heuristics (A/B of vidar_amd/gemm_tuning.py)")
     ap.add_argument("--tunableop-file", help="where TunableOp writes the solutions it found (default /tmp/...)")
     return ap.parse_args()
+
+
+def relaunch_command(args, argv, port=None):
+    """`python bench.py --gpus N` without a launcher: the command that re-runs this script as N ranks of ONE node
+    (what the driver's own multi-GPU command looks like), or None when no re-launch is needed.  A rank environment
+    (WORLD_SIZE from torch.distributed.run) always wins -- then --gpus must agree with it."""
+    if "WORLD_SIZE" in os.environ or args.cpu_baseline_only:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if not args.cpu_baseline_only and args.gpus != world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        return None
+    if args.gpus <= 1:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), *argv]
 
 
 def synthetic_images(seed, T, num_cams, hw, device, scale=1):
@@ -394,17 +417,17 @@ def kernel_rooflines(dev):
             2 * vol + N * M * 16 + N * M * 4 * (2 + 1026 * 6))
         add(f"dvr.render_forward[M={M}]",
             hip_time(lambda: dvr.render_forward(sigma, origin, points, tindex, [T_, 16, 200, 200], "train")),
-            vol + N * M * 24 + cnt * 4, bound="fp64 issue (sequential DDA per lane), not HBM")
+            vol + N * M * 24 + cnt * 4,
+            bound=("step-parallel traversal (per-axis tMax chains + lane-per-step integration), instruction issue, not HBM"
+                   if N * M <= 24576 else "fp64 issue (sequential DDA per lane), not HBM"))
         # the bound as a NUMBER: a ray is a serial chain of fp64 traversal steps, a wave lasts as long as its longest ray, and
         # with <= 1 wave per SIMD (469 waves at 30 000 rays) the launch lasts as long as its longest wave
         rows[-1]["serial_chain"] = dict(longest_ray_steps=longest, total_steps=cnt,
                                         us_per_step_of_longest_ray=round(rows[-1]["avg_ms"] * 1e3 / max(longest, 1), 3),
                                         waves=(N * M + 63) // 64, simds=1024)
         add(f"dvr.render[M={M}]", hip_time(lambda: dvr.render(sigma, origin, points, tindex, "l1")),
-            2 * vol + N * M * 24 + cnt * 12, bound="fp64 issue + per-lane atomics, not HBM")
-        rows[-1]["serial_chain"] = dict(longest_ray_steps=longest, total_steps=cnt,
-                                        us_per_step_of_longest_ray=round(rows[-1]["avg_ms"] * 1e3 / max(longest, 1), 3),
-                                        waves=(N * M + 63) // 64, simds=1024)
+            2 * vol + N * M * 24 + cnt * 12,
+            bound="step-parallel traversal, lane-per-step fp32 atomics (coalesced along a ray), not HBM")
         del out, em, live
     from vidar_amd.third_lib.chamferdist import knn_points
     rng = np.random.default_rng(0)
@@ -429,6 +452,44 @@ def kernel_rooflines(dev):
                   "(profiles/r03_pmc_msda_sca); reported vs HBM")
         add(f"msda_bwd[{name}]", hip_time(lambda: _msda_backward(value, sh, lsi, loc, w, go)),
             msda_bwd_bytes(B, Nv, 8, 32, Nq, L, P))
+    return rows
+
+
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # MI355X_MICROARCH.md: dense fp32 / bf16 matrix-core peaks
+
+
+def gemm_rooflines(dev):
+    """`roofline_gemm`: the hand-written MFMA GEMM (csrc/gemm_mfma.hip) at the two shapes that matter -- the attention
+    value projection the north star assigns to MFMA ([6*30825, 256] x [256, 256], spatial_cross_attention.py:333-340)
+    and the largest 1x1 convolution of the backbone (layer3 conv3: 24 x [1024, 256] x [256, 5800]) -- in both arithmetic
+    modes, each against BOTH its rooflines: HBM (compulsory bytes / ms vs 8 TB/s) and the matrix cores (MFMA flops
+    actually issued / ms vs the dense peak of the instruction: fp32 157 TF/s; bf16x3 issues 3 bf16 MFMAs per product
+    -> 3 x 2MNK vs 2.5 PF/s), next to the library kernel on the same operands."""
+    from vidar_amd import gemm as G
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *sh: torch.rand(*sh, device=dev, generator=g) * 2 - 1
+    rows = []
+
+    def add(name, flops, nbytes, fns):
+        for mode, fn in fns.items():
+            ms = hip_time(fn)
+            mult, peak = (3.0, MFMA_PEAK_TFLOPS["bf16"]) if mode == "bf16x3" else (1.0, MFMA_PEAK_TFLOPS["f32"])
+            rows.append(dict(kernel=name, mode=mode, avg_ms=round(ms, 4), bytes=int(nbytes), flops=flops,
+                             hbm=dict(achieved=round(nbytes / ms / 1e6, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                      frac=round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4)),
+                             mfma=dict(achieved=round(mult * flops / ms / 1e9, 1), peak=peak, unit="TFLOP/s",
+                                       frac=round(mult * flops / ms / 1e9 / peak, 4),
+                                       note="library kernel: its own fp32 MFMA instructions" if mode == "lib" else None)))
+    M, K, N = 6 * 30825, 256, 256
+    x, w, b = rnd(M, K), rnd(N, K) * 0.1, rnd(N)
+    add(f"value_proj fwd [{M},{K}]x[{K},{N}]", 2.0 * M * N * K, 4 * (M * K + M * N + N * K),
+        {"lib": lambda: torch.addmm(b, x, w.t()), "f32": lambda: G.linear_forward(x, w, b, False, G.F32),
+         "bf16x3": lambda: G.linear_forward(x, w, b, False, G.BF16X3)})
+    Bn, Co, Ci, HW = 24, 1024, 256, 5800
+    wc, xc = rnd(Co, Ci) * 0.05, rnd(Bn, Ci, HW)
+    add(f"layer3 conv3 {Bn}x[{Co},{Ci}]x[{Ci},{HW}]", 2.0 * Bn * Co * Ci * HW, 4 * (Bn * Ci * HW + Bn * Co * HW + Co * Ci),
+        {"lib": lambda: torch.bmm(wc.view(1, Co, Ci).expand(Bn, -1, -1), xc),
+         "f32": lambda: G.conv_forward(wc, xc, precision=G.F32), "bf16x3": lambda: G.conv_forward(wc, xc, precision=G.BF16X3)})
     return rows
 
 
@@ -563,6 +624,11 @@ def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers
 
 def main():
     args = parse()
+    cmd = relaunch_command(args, sys.argv[1:])
+    if cmd is not None:                  # `python bench.py --gpus N` called plainly: become N RCCL ranks
+        print(f"[bench] --gpus {args.gpus} without a launcher: re-running as {' '.join(cmd[1:8])} ...", file=sys.stderr,
+              flush=True)
+        os.execv(cmd[0], cmd)
     if args.cpu_baseline_only:
         # never drive the host out of memory: cap this child's address space (a full-size CPU step took a box down)
         try:
@@ -596,6 +662,9 @@ def main():
     extras = []
     t_extras = time.perf_counter()
     for entry in [c for c in args.extra_configs.split(",") if c]:
+        rigor = entry.endswith("!")
+        entry = entry.rstrip("!")
+        xsteps, xwarm = (args.steps, args.warmup) if rigor else (args.extra_steps, args.extra_warmup)
         head, _, xgemm = entry.partition(":")
         name, _, xs = head.partition("@")
         xspg = int(xs) if xs else spg
@@ -613,7 +682,7 @@ def main():
                            "skipped": f"extra-config time budget ({args.extra_budget_s:.0f} s) spent"})
             continue
         try:
-            r = run_config(name, args, rank, local, world, dev, args.extra_steps, args.extra_warmup, with_markers=False,
+            r = run_config(name, args, rank, local, world, dev, xsteps, xwarm, with_markers=False,
                            spg=xspg, gemm_mode=xgemm, tune=False)
         except Exception as e:                                              # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
@@ -627,9 +696,9 @@ def main():
         if err:
             extras.append({"config": name, "samples_per_gpu": xspg, "gemm": xgemm or main_run["gemm"], "error": err})
             continue
-        rec = {"config": name, "samples_per_gpu": xspg, "value": world * xspg * args.extra_steps / r["elapsed"],
-               "unit": "samples/s", "ms_per_step": r["elapsed"] / args.extra_steps * 1e3, "steps": args.extra_steps,
-               "warmup": args.extra_warmup, "n_gpus": world, "global_batch": world * xspg,
+        rec = {"config": name, "samples_per_gpu": xspg, "value": world * xspg * xsteps / r["elapsed"],
+               "unit": "samples/s", "ms_per_step": r["elapsed"] / xsteps * 1e3, "steps": xsteps,
+               "warmup": xwarm, "n_gpus": world, "global_batch": world * xspg,
                "cameras": r["cfg"]["num_cams"], "img_hw": list(r["cfg"]["img_hw"]), "gemm": r["gemm"],
                "dtype": GEMM_DTYPE[r["gemm"]], "peak_mem_gb": round(r["peak_mem_gb"], 2),
                "peak_reserved_gb": round(r["peak_reserved_gb"], 2)}
@@ -639,7 +708,7 @@ def main():
             ach = dv["bytes_per_call"] / (dv["avg_ms"] * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "kernel": dn, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBPS, "avg_ms": dv["avg_ms"],
-                               "launches_per_step": dv["calls"] / args.extra_steps}
+                               "launches_per_step": dv["calls"] / xsteps}
         if r["ddp"]:
             rec["ddp"] = r["ddp"]
         extras.append(rec)
@@ -698,6 +767,12 @@ def main():
                 import traceback
                 traceback.print_exc()
                 out["roofline_kernels_error"] = f"{type(e).__name__}: {e}"
+            try:
+                out["roofline_gemm"] = gemm_rooflines(dev)
+            except Exception as e:                                          # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                out["roofline_gemm_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline and not grouped:
             print("[bench] cpu baseline (child process) ...", file=sys.stderr, flush=True)
             try:

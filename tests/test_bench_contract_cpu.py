@@ -164,3 +164,43 @@ def test_grouped_timing_and_ddp_block_two_ranks_gloo():
     for i in (a["info"], b["info"]):
         assert i["world_size"] == 2 and i["backend"] == "gloo" and i["allreduce_bytes_per_step"] > 0
         assert i["has_rebuilt_buckets"] and sum(i["rebuilt_bucket_bytes"]) == sum(i["initial_bucket_bytes"])
+
+
+def test_plain_gpus_n_relaunches_as_n_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must not silently measure ONE rank: it re-executes itself under
+    torch.distributed.run with N ranks on 127.0.0.1 (the driver's own multi-GPU command line); inside a launcher
+    (WORLD_SIZE set) nothing is re-launched, and a --gpus that disagrees with the launcher fails loudly."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    old = sys.argv
+    try:
+        argv = ["--gpus", "4", "--steps", "20", "--warmup", "5"]
+        sys.argv = ["bench.py", *argv]
+        a = bench.parse()
+        monkeypatch.delenv("WORLD_SIZE", raising=False)
+        cmd = bench.relaunch_command(a, argv, port=29512)
+        assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+        assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29512"
+        assert cmd[-len(argv) - 1].endswith("bench.py") and cmd[-len(argv):] == argv
+        monkeypatch.setenv("WORLD_SIZE", "4")
+        assert bench.relaunch_command(a, argv) is None
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        with pytest.raises(SystemExit):
+            bench.relaunch_command(a, argv)
+        monkeypatch.delenv("WORLD_SIZE")
+        sys.argv = ["bench.py", "--gpus", "1"]
+        assert bench.relaunch_command(bench.parse(), ["--gpus", "1"]) is None
+    finally:
+        sys.argv = old
+
+
+def test_relaunched_ranks_reach_the_rank_environment():
+    """end to end on this CPU box: the re-launch really starts N ranks (each then refuses to run without a GPU --
+    the measured path has no CPU form -- which is what the ranks' output must say, N times)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    out = r.stderr + r.stdout
+    assert r.returncode != 0 and "re-running as" in out and out.count("needs a GPU") >= 2
