@@ -348,9 +348,10 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, 
 
 // epilogue of one tile: accumulator register r of MFMA tile (i, j) is row m = m0 + wm + 32i + (r&3) + 8(r>>2) + 4h, column
 // n = n0 + wn + 32j + (lane&31): one store instruction writes two rows of 32 consecutive floats (two full 128-byte
-// lines).  Buffer addressing again: the lane's part of the offset is ONE register, the register's part is scalar;
-// the descriptors end at the matrix' last element, so rows past M are dropped (stores) / read as 0 (loads) by the
-// hardware's range check and only the column test n < N remains, once per column tile.
+// lines).  Buffer addressing again: the lane's part of the offset is ONE register, the register's part is scalar for
+// the loads (a garbage load of a row >= M can only feed a row that is never stored) and added to the vector offset
+// for the stores; the descriptors end at the matrix' last element, so rows past M are dropped (stores) / read as 0
+// (loads) by the hardware's range check and only the column test n < N remains, once per column tile.
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, const Tile& T, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -399,8 +400,11 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmAr
             y = y * sc[r] + sh[r] + rs[r];
             if (g.relu && !(y > 0.0f)) y = 0.0f;
           }
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC, voC,
-                                                  (uint32_t)((row * (uint32_t)ldc + 32 * j) * 4), 0);
+          // the row part of a STORE's offset travels in the vector offset, which the descriptor's range check covers
+          // by definition (a scalar offset is only checked through the gfx9 rule num_records - soffset): one
+          // v_add per store instead of resting the drop of rows >= M on that hardware detail
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC,
+                                                  voC + (uint32_t)((row * (uint32_t)ldc + 32 * j) * 4), 0, 0);
         }
       }
     }
@@ -490,15 +494,16 @@ void launch(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStream_
   else hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_MN, LAY_MN>), grid, dim3(THREADS), 0, st, g);
 }
 
-int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+int num_cus() {                       // of the CURRENT device (cached per device id)
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
+    cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
   }
-  return n;
+  return cached[dev];
 }
 
 // how many k-splits a reduced product gets: enough workgroups for ~2 per CU, k chunks of at least 4 k-steps
@@ -560,6 +565,10 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   const int Z = batch * g.splits;
   g.slabs = (reduce && Z > 1) ? 1 : 0;
   if ((int64_t)g.tiles_m * g.tiles_n * Z > 0x3fffffff) return VIDAR_ERR_BAD_ARG;
+  g.total = g.tiles_m * g.tiles_n * Z;
+  // a reduced product writes slabs and the reduction kernel applies the epilogue on [M, N] of ONE output: batch and
+  // residual strides have no meaning there
+  if (reduce && (strideC != 0 || strideR != 0) && batch > 1) return VIDAR_ERR_BAD_ARG;
   GemmArgs k = g;
   if (g.slabs) {
     if (workspace == nullptr || workspace_bytes < (size_t)Z * M * N * sizeof(float)) return VIDAR_ERR_BAD_ARG;

@@ -72,6 +72,40 @@ def _f32c(t, what):
     return t
 
 
+_LD_MAX = 1 << 22          # leading dimensions the kernel's 31-bit per-workgroup byte offsets allow (gemm_mfma.hip)
+_KLD_MAX = 1 << 29         # contraction length x leading dimension of an MN-major operand
+
+
+def operand_ok(t, layout, contraction) -> bool:
+    """can the 2-D (or [B, r, c]) tensor `t` be handed to vidar_gemm_f32 as it is?  The kernel takes any leading
+    dimension >= the row length (row-sliced views are fine) but needs a unit last stride, an un-broadcast row stride
+    and offsets that fit its 31-bit addressing; everything else takes the library product instead (bricks.Linear,
+    backbones.conv1x1_bn_act in "auto" mode) or is made contiguous first (the wrappers below)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() >= 2 and t.stride(-1) == 1):
+        return False
+    ld = t.stride(-2)
+    if ld < t.shape[-1] or ld >= _LD_MAX:
+        return False
+    return layout == K_MAJOR or contraction * ld < _KLD_MAX
+
+
+def _operand(t, layout, contraction, what):
+    """`t` as the kernel can read it: itself when operand_ok, otherwise a contiguous copy (a transposed / expanded view
+    used to be an error here)"""
+    _f32c(t, what) if t.stride(-1) == 1 else None
+    if operand_ok(t, layout, contraction):
+        return t
+    if not t.is_cuda:
+        raise RuntimeError(f"vidar_gemm: {what} must be a CUDA tensor (no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"vidar_gemm: {what} must be float32, got {t.dtype}")
+    c = t.contiguous()
+    if not operand_ok(c, layout, contraction):
+        raise ValueError(f"vidar_gemm: {what} {tuple(t.shape)} exceeds the kernel's addressing range "
+                         f"(leading dimension < 2^22, contraction x leading dimension < 2^29)")
+    return c
+
+
 def gemm_raw(A, lda, a_layout, B, ldb, b_layout, C, ldc, M, N, K, *, batch=1, sA=0, sB=0, sC=0, scale=None, shift=None,
              vec_axis=0, residual=None, ldr=0, sR=0, relu=False, precision=F32, reduce=False, name="gemm"):
     """one call of vidar_gemm_f32 on torch tensors (pointers are taken as they are: the caller states the geometry)"""
@@ -96,9 +130,9 @@ def gemm_raw(A, lda, a_layout, B, ldb, b_layout, C, ldc, M, N, K, *, batch=1, sA
 # ---- nn.Linear on [rows, K] activations -----------------------------------------------------------------------------
 def linear_forward(x2, weight, bias=None, relu=False, precision=F32):
     """relu?(x2 [M,K] @ weight[N,K]^T + bias) -> [M,N]"""
-    _f32c(x2, "x"); _f32c(weight, "weight")
     M, K = x2.shape
     N = weight.shape[0]
+    x2 = _operand(x2, K_MAJOR, K, "x"); weight = _operand(weight, K_MAJOR, K, "weight")
     y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
     if M == 0:
         return y
@@ -109,9 +143,9 @@ def linear_forward(x2, weight, bias=None, relu=False, precision=F32):
 
 def linear_grad_input(g2, weight, precision=F32):
     """g2 [M,N] @ weight [N,K] -> [M,K]"""
-    _f32c(g2, "grad_out"); _f32c(weight, "weight")
     M, N = g2.shape
     K = weight.shape[1]
+    g2 = _operand(g2, K_MAJOR, N, "grad_out"); weight = _operand(weight, MN_MAJOR, N, "weight")
     gx = torch.empty((M, K), dtype=torch.float32, device=g2.device)
     if M == 0:
         return gx
@@ -121,14 +155,19 @@ def linear_grad_input(g2, weight, precision=F32):
 
 def linear_grad_weight(g2, x2, precision=F32):
     """g2 [M,N]^T @ x2 [M,K] -> [N,K]  (the contraction runs over the rows: split over K', slabs summed in order)"""
-    _f32c(g2, "grad_out"); _f32c(x2, "x")
     M, N = g2.shape
     K = x2.shape[1]
+    g2 = _operand(g2, MN_MAJOR, M, "grad_out"); x2 = _operand(x2, MN_MAJOR, M, "x")
     gw = torch.empty((N, K), dtype=torch.float32, device=g2.device)
     if M == 0:
         return gw.zero_()
     return gemm_raw(g2, g2.stride(0), MN_MAJOR, x2, x2.stride(0), MN_MAJOR, gw, K, N, K, M, precision=precision,
                     reduce=True, name="gemm_linear_dw")
+
+
+def linear_grad_weight_ok(g2, x2) -> bool:
+    """both operands of linear_grad_weight are readable in place (no copy, no addressing overflow)"""
+    return g2.dim() == 2 and x2.dim() == 2 and operand_ok(g2, MN_MAJOR, g2.shape[0]) and operand_ok(x2, MN_MAJOR, x2.shape[0])
 
 
 def _colsum(g2):

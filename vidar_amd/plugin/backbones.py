@@ -280,8 +280,12 @@ def conv1x1_bn_act(conv, bn, x, residual=None, relu=False):
     # "auto": only the block's closing convolution (the one with a residual) takes the fused MFMA kernel -- there the
     # epilogue saves a 3-tensor affine_act pass; the other 1x1 convolutions are faster as library GEMM + affine_act
     fuse = G.own_kernels(m) or (m == "auto" and residual is not None and _AUTO_FUSE_RES)
+    hw = (x.shape[2] // conv.stride[0]) * (x.shape[3] // conv.stride[1]) if x.dim() == 4 else 0
+    # (beyond the kernel's addressing range -- H*W >= 2^22 or channels x H*W >= 2^29, gemm.operand_ok -- the library
+    #  convolution runs as in every other mode)
+    in_range = 0 < hw < (1 << 22) and max(conv.in_channels, conv.out_channels) * hw < (1 << 29)
     if (not fuse or not x.is_cuda or bn.weight.requires_grad or conv.bias is not None or conv.kernel_size != (1, 1)
-            or conv.padding != (0, 0) or conv.groups != 1):
+            or conv.padding != (0, 0) or conv.groups != 1 or not in_range):
         return bn(conv(x), residual=residual, relu=relu)
     if conv.stride != (1, 1):
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]]

@@ -75,7 +75,10 @@ class _LinearColsum(torch.autograd.Function):
             gx = g2 @ w
         if ctx.needs_input_grad[1]:
             # "auto": the exact-fp32 split-K MFMA kernel (4 x the library's best solution for these tall contractions)
-            gw = _gemm.linear_grad_weight(g2, x2, _gemm.F32) if _gemm.mode() == "auto" else (x2.t() @ g2).t()
+            # (operands the kernel cannot read in place -- a transposed / expanded view, a leading dimension beyond its
+            #  addressing range -- take the library product like every other mode)
+            own = _gemm.mode() == "auto" and _gemm.linear_grad_weight_ok(g2, x2)
+            gw = _gemm.linear_grad_weight(g2, x2, _gemm.F32) if own else (x2.t() @ g2).t()
         gb = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)
         check(lib().vidar_colsum_f32(ptr(g2), ptr(gb), ctypes.c_int64(g2.shape[0]), int(g2.shape[1]), stream_of(g2)),
               "colsum")
