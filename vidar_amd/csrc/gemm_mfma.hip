@@ -348,10 +348,10 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, 
 
 // epilogue of one tile: accumulator register r of MFMA tile (i, j) is row m = m0 + wm + 32i + (r&3) + 8(r>>2) + 4h, column
 // n = n0 + wn + 32j + (lane&31): one store instruction writes two rows of 32 consecutive floats (two full 128-byte
-// lines).  Buffer addressing again: the lane's part of the offset is ONE register, the register's part is scalar for
-// the loads (a garbage load of a row >= M can only feed a row that is never stored) and added to the vector offset
-// for the stores; the descriptors end at the matrix' last element, so rows past M are dropped (stores) / read as 0
-// (loads) by the hardware's range check and only the column test n < N remains, once per column tile.
+// lines).  Buffer addressing again: the lane's part of the offset is ONE register, the register's part is scalar;
+// the descriptors end at the matrix' last element, so rows past M read as 0 (a garbage load could only feed a row that
+// is never stored anyway) and their stores are dropped by the hardware's range check -- and, independently of it,
+// by an explicit row predicate; the column test n < N is made once per column tile.
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, const Tile& T, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -363,6 +363,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmAr
   const bool epi = !g.slabs;
   const bool by_n = epi && g.vec_axis == 0, by_m = epi && g.vec_axis == 1;
   const int rows_left = g.M - m0, cols_left = g.N - n0;                      // >= 1
+  const int mleft = rows_left - wm - 4 * h;                                  // rows of this lane's part of the tile inside M
   const __amdgpu_buffer_rsrc_t rsC = make_rsrc(C + (int64_t)m0 * ldc + n0, ((int64_t)(rows_left - 1) * ldc + cols_left) * 4);
   const uint32_t voC = (uint32_t)(((wm + 4 * h) * (uint32_t)ldc + wn + l31) * 4);
   const bool has_res = epi && g.residual != nullptr;
@@ -400,11 +401,11 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmAr
             y = y * sc[r] + sh[r] + rs[r];
             if (g.relu && !(y > 0.0f)) y = 0.0f;
           }
-          // the row part of a STORE's offset travels in the vector offset, which the descriptor's range check covers
-          // by definition (a scalar offset is only checked through the gfx9 rule num_records - soffset): one
-          // v_add per store instead of resting the drop of rows >= M on that hardware detail
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC,
-                                                  voC + (uint32_t)((row * (uint32_t)ldc + 32 * j) * 4), 0, 0);
+          // rows >= M: an explicit predicate on top of the descriptor's range check (the row part of the offset is a
+          // scalar offset, which the hardware only checks through the gfx9 rule num_records - soffset)
+          if (row < mleft)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC, voC,
+                                                    (uint32_t)((row * (uint32_t)ldc + 32 * j) * 4), 0);
         }
       }
     }
