@@ -384,6 +384,9 @@ if __name__ == "__main__":
     if os.environ.get("VIDAR_MSDA_ITEM_ORDER") is not None:          # A/B of the gather kernels' item order (0 banded, 1 head-major)
         from vidar_amd._lib import lib
         lib().vidar_msda_set_item_order(int(os.environ["VIDAR_MSDA_ITEM_ORDER"]))
+    if os.environ.get("VIDAR_GEMM_VARIANT") is not None:               # A/B of the GEMM kernel's structure (0 classic, 1 / 2 wave-specialised)
+        from vidar_amd._lib import lib
+        lib().vidar_gemm_set_variant(int(os.environ["VIDAR_GEMM_VARIANT"]))
     which = sys.argv[1:] or ["dvr", "knn", "msda", "lr", "ray"]
     print(json.dumps({"device": torch.cuda.get_device_name(0)}))
     for w in which:

@@ -452,6 +452,151 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form (round 5).  The kernel above gives every wave every job -- global loads, the bf16 split, LDS
+// stores, fragment reads, MFMAs, the epilogue -- with two barriers per k-step, and its phases ADD UP instead of
+// overlapping (profiles/r04_kbench_gemm_ablate*.log): the workgroups of a CU run in lockstep, and because loads and
+// stores share the in-order vmcnt counter the 64 epilogue stores of a tile stand between its successor's second k-step
+// and the matrix cores.  Here a 512-thread workgroup (one per CU: a matrix wave and a staging wave on every SIMD) splits
+// the roles:
+//   waves 4-7  PRODUCERS  global -> registers (two k-steps ahead, two register sets) -> split -> LDS stage (g & 1)
+//   waves 0-3  CONSUMERS  fragment reads + MFMAs of stage (g & 1), then the tile's epilogue
+// over ONE flat stream of k-steps g = 0, 1, ... that runs across the tiles a workgroup walks, with ONE barrier per
+// k-step (LDS-only: `s_waitcnt lgkmcnt(0); s_barrier` -- the prefetch loads and the epilogue stores stay in flight
+// across it, which __syncthreads()' vmcnt(0) would drain):
+//   barrier g:  producers have filled stage g & 1 with step g  |  consumers have finished step g - 1 (stage (g-1) & 1)
+// so after it the consumers compute step g while the producers overwrite stage (g+1) & 1 with step g + 1.  While the
+// consumers store a tile, the producers are already staging the next tile's first two k-steps; the consumers' vmcnt
+// only ever counts their own stores and is never waited on.
+constexpr int WS_THREADS = 512;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// a position in the flat k-step stream of one workgroup
+template <int PREC, int ALAY, int BLAY>
+struct Cursor {
+  int t;          // tile number (blockIdx + n * grid); >= total: exhausted
+  int k0;
+  Tile T;
+  __device__ __forceinline__ void start(const GemmArgs& g, int t0) {
+    t = t0;
+    while (t < g.total) {
+      T = decode_tile<PREC, ALAY, BLAY>(g, t);
+      if (T.kbeg < T.kend) break;
+      t += (int)gridDim.x;
+    }
+    k0 = (t < g.total) ? T.kbeg : 0;
+  }
+  __device__ __forceinline__ bool valid(const GemmArgs& g) const { return t < g.total; }
+  __device__ __forceinline__ void advance(const GemmArgs& g) {
+    k0 += BK;
+    if (k0 >= T.kend) start(g, t + (int)gridDim.x);
+  }
+};
+
+template <int PREC, int ALAY, int BLAY>
+__global__ __launch_bounds__(WS_THREADS, 2) void gemm_mfma_ws_kernel(GemmArgs g) {
+  constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
+  constexpr int IMG_DWORDS = Geo<PREC>::IMG_DWORDS;
+  constexpr int STAGE_DWORDS = 2 * IMGS * IMG_DWORDS;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE_DWORDS];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x >= g.total) return;
+
+  if (wave >= 4) {
+    // ------------------------------------------------ producers ------------------------------------------------
+    const int ptid = tid - 256;
+    const uint32_t voa = ALAY == LAY_K ? voff_kmajor<PREC>(g.lda, ptid) : voff_mnmajor<PREC>(g.lda, ptid);
+    const uint32_t vob = BLAY == LAY_K ? voff_kmajor<PREC>(g.ldb, ptid) : voff_mnmajor<PREC>(g.ldb, ptid);
+    Staged<PREC> sa0, sb0, sa1, sb1;
+    Cursor<PREC, ALAY, BLAY> rd;                       // next k-step to REQUEST
+    rd.start(g, (int)blockIdx.x);
+    // how many k-steps this workgroup owns in total (= barriers both roles execute)
+    int steps = 0;
+    for (int t = (int)blockIdx.x; t < g.total; t += (int)gridDim.x) {
+      const Tile T = decode_tile<PREC, ALAY, BLAY>(g, t);
+      steps += (T.kend > T.kbeg) ? (T.kend - T.kbeg + BK - 1) / BK : 0;
+    }
+    if (rd.valid(g)) { fetch<PREC, ALAY, BLAY>(sa0, sb0, g, rd.T, rd.k0, ptid, voa, vob); rd.advance(g); }
+    if (rd.valid(g)) { fetch<PREC, ALAY, BLAY>(sa1, sb1, g, rd.T, rd.k0, ptid, voa, vob); rd.advance(g); }
+    for (int gs = 0; gs < steps; gs += 2) {
+      {
+        uint32_t* imgA = lds;
+        uint32_t* imgB = lds + IMGS * IMG_DWORDS;
+        if (ALAY == LAY_K) store_kmajor<PREC>(sa0, imgA, ptid); else store_mnmajor<PREC>(sa0, imgA, ptid);
+        if (BLAY == LAY_K) store_kmajor<PREC>(sb0, imgB, ptid); else store_mnmajor<PREC>(sb0, imgB, ptid);
+        if (rd.valid(g)) { fetch<PREC, ALAY, BLAY>(sa0, sb0, g, rd.T, rd.k0, ptid, voa, vob); rd.advance(g); }
+        lds_barrier();
+      }
+      if (gs + 1 < steps) {
+        uint32_t* imgA = lds + STAGE_DWORDS;
+        uint32_t* imgB = lds + STAGE_DWORDS + IMGS * IMG_DWORDS;
+        if (ALAY == LAY_K) store_kmajor<PREC>(sa1, imgA, ptid); else store_mnmajor<PREC>(sa1, imgA, ptid);
+        if (BLAY == LAY_K) store_kmajor<PREC>(sb1, imgB, ptid); else store_mnmajor<PREC>(sb1, imgB, ptid);
+        if (rd.valid(g)) { fetch<PREC, ALAY, BLAY>(sa1, sb1, g, rd.T, rd.k0, ptid, voa, vob); rd.advance(g); }
+        lds_barrier();
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------- consumers ----------------------------------------------------
+  const int lane = tid & 63;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int l31 = lane & 31, h = lane >> 5;
+  int gs = 0;                                            // flat k-step counter: stage = gs & 1
+  for (int t = (int)blockIdx.x; t < g.total; t += (int)gridDim.x) {
+    const Tile T = decode_tile<PREC, ALAY, BLAY>(g, t);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int k0 = T.kbeg; k0 < T.kend; k0 += BK, ++gs) {
+      lds_barrier();
+      const uint32_t* imgA = lds + (gs & 1) * STAGE_DWORDS;
+      const uint32_t* imgB = imgA + IMGS * IMG_DWORDS;
+#pragma unroll
+      for (int s = 0; s < Geo<PREC>::NS; ++s) {
+        u32x4 fa[2][IMGS], fb[2][IMGS];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int p = 0; p < IMGS; ++p) {
+            fa[i][p] = frag<PREC, ALAY>(imgA + p * IMG_DWORDS, wm + 32 * i + l31, s, h);
+            fb[i][p] = frag<PREC, BLAY>(imgB + p * IMG_DWORDS, wn + 32 * i + l31, s, h);
+          }
+        if (PREC == PREC_BF16X3) {
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, fa[i][term == 0 ? IMGS - 1 : 0]);
+                const bf16x8 b = __builtin_bit_cast(bf16x8, fb[j][term == 1 ? IMGS - 1 : 0]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i][j], 0, 0, 0);
+              }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const f32x4 bf = __builtin_bit_cast(f32x4, fb[j][0]), af = __builtin_bit_cast(f32x4, fa[i][0]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u], bf[u], acc[i][j], 0, 0, 0);
+              }
+        }
+      }
+    }
+    epilogue(acc, g, T, tid);
+  }
+}
+
 // C[m, n] = epilogue( sum_z slab[z][m, n] ).  64 float4 columns x 4 z-groups per workgroup: a thread sums every fourth
 // slab of its four elements (16-byte loads, Z/4 deep instead of Z), the four partial sums are combined through LDS in
 // z-group order -- the order of the additions is fixed, the result is deterministic.
@@ -488,6 +633,17 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __re
 }
 
 template <int PREC>
+void launch_ws(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStream_t st) {
+  if (a_layout == LAY_K && b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_ws_kernel<PREC, LAY_K, LAY_K>), grid, dim3(WS_THREADS), 0, st, g);
+  else if (a_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_ws_kernel<PREC, LAY_K, LAY_MN>), grid, dim3(WS_THREADS), 0, st, g);
+  else if (b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_ws_kernel<PREC, LAY_MN, LAY_K>), grid, dim3(WS_THREADS), 0, st, g);
+  else hipLaunchKernelGGL((gemm_mfma_ws_kernel<PREC, LAY_MN, LAY_MN>), grid, dim3(WS_THREADS), 0, st, g);
+}
+
+int g_gemm_variant = 1;      // 0: every wave does every job (round 4); 1 / 2: wave-specialised producer / consumer
+                             // workgroups, one / two of them per CU
+
+template <int PREC>
 void launch(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStream_t st) {
   if (a_layout == LAY_K && b_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_K>), grid, dim3(THREADS), 0, st, g);
   else if (a_layout == LAY_K) hipLaunchKernelGGL((gemm_mfma_kernel<PREC, LAY_K, LAY_MN>), grid, dim3(THREADS), 0, st, g);
@@ -521,6 +677,12 @@ int pick_splits(int M, int N, int K, int batch, int bk) {
 }  // namespace
 
 extern "C" {
+
+int vidar_gemm_set_variant(int variant) {
+  const int prev = g_gemm_variant;
+  g_gemm_variant = (variant < 0 || variant > 2) ? 1 : variant;
+  return prev;
+}
 
 int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce) {
   if (!reduce) return 1;
@@ -579,10 +741,18 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   // one residency of the chip: 3 workgroups per CU (launch bounds: 3 waves per SIMD), a multiple of 8 so that t & 7
   // stays the workgroup's XCD for every tile it walks.  (Measured against one workgroup per tile and against fetching
   // the next tile after the epilogue: within noise of each other on MI355X, profiles/r04_kbench_gemm_*.)
-  const int resident = num_cus() * 3 / 8 * 8;
-  dim3 grid(k.total > resident ? resident : k.total);
-  if (precision == PREC_BF16X3) launch<PREC_BF16X3>(k, a_layout, b_layout, grid, st);
-  else launch<PREC_F32>(k, a_layout, b_layout, grid, st);
+  if (g_gemm_variant >= 1) {
+    // one (two) 512-thread workgroup(s) per CU (a multiple of 8 keeps t & 7 = the XCD for every tile a workgroup walks)
+    const int resident = num_cus() * g_gemm_variant / 8 * 8;
+    dim3 grid(k.total > resident ? resident : k.total);
+    if (precision == PREC_BF16X3) launch_ws<PREC_BF16X3>(k, a_layout, b_layout, grid, st);
+    else launch_ws<PREC_F32>(k, a_layout, b_layout, grid, st);
+  } else {
+    const int resident = num_cus() * 3 / 8 * 8;
+    dim3 grid(k.total > resident ? resident : k.total);
+    if (precision == PREC_BF16X3) launch<PREC_BF16X3>(k, a_layout, b_layout, grid, st);
+    else launch<PREC_F32>(k, a_layout, b_layout, grid, st);
+  }
   if (g.slabs) {
     const int64_t total = (int64_t)M * N;
     int blocks = (int)((total / 4 + 1 + 63) / 64);
