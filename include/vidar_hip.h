@@ -372,9 +372,10 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
                    void* stream);
 int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce);
 size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce);
-/* A/B switch of the kernel's structure: 1 (default) = wave-specialised workgroups (4 staging waves + 4 matrix /
- * epilogue waves, one LDS-only barrier per k-step, csrc/gemm_mfma.hip), 0 = the round-4 form in which every wave does
- * every job.  Same arithmetic, same tile order: results are bit-identical.  Returns the previous value. */
+/* A/B switch of the kernel's structure: 0 (default) = every wave does every job; 1 / 2 = wave-specialised workgroups
+ * (4 staging waves + 4 matrix / epilogue waves, LDS double buffer, one LDS-only barrier per k-step), one / two per CU
+ * (csrc/gemm_mfma.hip; measured equal or slower: profiles/r05_kbench_gemm_variants.log).  Same arithmetic, same tile
+ * order: results are bit-identical.  Returns the previous value. */
 int vidar_gemm_set_variant(int variant);
 
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,

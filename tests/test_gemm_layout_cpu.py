@@ -3,7 +3,8 @@ numpy index arithmetic and checked against A @ B for all four operand layouts an
 
 What is restated (and must be kept in step with the kernel): the staging maps of `load_kmajor` / `load_mnmajor` /
 `store_kmajor` / `store_mnmajor` (which element a thread holds and where it lands in the image), the image geometry
-`Geo<PREC>` (row stride 36 / 20 dwords, 136-dword unit rows), `frag()` (units 8s + 4h + {0..3} of a row), the operand
+`Geo<PREC>` (K-major row stride 36 dwords in fp32 mode; 16 dwords with XOR-swizzled 16-byte chunks in bf16 mode;
+136-dword unit rows), `frag()` (units 8s + 4h + {0..3} of a row), the operand
 roles of `v_mfma_f32_32x32x16_bf16` / `v_mfma_f32_32x32x2_f32` (A[i = lane & 31][k = lane >> 5 ...], B[k][j = lane & 31]) and
 their accumulator layout (column lane & 31, row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), and the epilogue's row / column
 of a register.  The hi / lo split is not part of it (tests/test_gemm_cpu.py); values are carried exactly."""
@@ -18,7 +19,8 @@ IMG = 4608
 def emu(M,N,K,alay,blay,prec, A_store, B_store, lda, ldb):
     BK = 32
     CH = 2
-    KM = 20 if prec else 36
+    KM = 16 if prec else 36
+    swz = lambda r, chunk: (chunk ^ ((r >> 2) & 3)) << 2          # bf16 K-major: dword offset of a row's 16-byte chunk
     NS = 2 if prec else 4
     C = np.zeros((M,N))
     Af = A_store.ravel(); Bf = B_store.ravel()
@@ -39,7 +41,8 @@ def emu(M,N,K,alay,blay,prec, A_store, B_store, lda, ldb):
                             r=32*wave+lane//LPR+i*RPI; row=r0+r; k=k0+kq*4
                             v=[(P[row*ld+k+j] if (row<R and k+j<kend) else 0.0) for j in range(4)]
                             if prec:
-                                img2[r*KM+2*kq]=(v[0],v[1]); img2[r*KM+2*kq+1]=(v[2],v[3])
+                                pos=r*KM+(swz(r,kq>>1)|((kq&1)<<1))
+                                img2[pos]=(v[0],v[1]); img2[pos+1]=(v[2],v[3])
                             else:
                                 for j in range(4): img[r*KM+4*kq+j]=v[j]
                     else:
@@ -59,6 +62,7 @@ def emu(M,N,K,alay,blay,prec, A_store, B_store, lda, ldb):
             def frag(name,row,s,h):
                 img,img2,lay=imgs[name]
                 src = img2 if prec else img
+                if lay==0 and prec: return [src[row*KM+swz(row,2*s+h)+j] for j in range(4)]
                 if lay==0: return [src[row*KM+8*s+4*h+j] for j in range(4)]
                 return [src[(8*s+4*h+j)*MN+row] for j in range(4)]
             # per-wave MFMA emulation: D[i][j] += sum over lanes' k

@@ -21,10 +21,8 @@
 // 32 x 32 (64 accumulator registers).  Staging is global -> registers -> (split) -> LDS with the next k-tile's global
 // loads in flight under the MFMAs.  LDS images (a "unit" is one dword = one fp32 k or one bf16 k-pair; U = 32 units per
 // k-step in fp32 mode, 16 in bf16 mode):
-//   K-major  operand: [128 rows][U units + 4 pad]    row stride 144 / 80 B: ds_read_b128 fragments are conflict free
-//                     (slot stride 9 / 5 is odd, and each of the instruction's four 16-lane groups covers all 16
-//                     residues of the row index); the 8-byte staging stores of bf16 mode are 2-way conflicted
-//                     (SQ_LDS_BANK_CONFLICT = a third of the LDS cycles, with LDS active 26 % of the time)
+//   K-major  operand: fp32 [128 rows][32 units + 4 pad] (row stride 144 B, slot stride 9 odd: ds_read_b128 fragments
+//                     conflict free); bf16 [128 rows][16 units], unpadded, 16-byte chunks XOR-swizzled (Geo::KM_STRIDE)
 //   MN-major operand: [U units][128 rows + 8 pad]    four ds_read_b32 per fragment, 32 consecutive dwords per group
 // A lane's fragment is always the four units 8*s + 4*(lane>>5) + {0..3} of its row -- in bf16 mode they ARE the
 // eight consecutive k of one 32x32x16 operand, in fp32 mode they feed four 32x32x2 MFMAs whose two k slots
@@ -67,7 +65,12 @@ constexpr int MN_STRIDE = 128 + 8;        // dwords per unit row of an MN-major 
 template <int PREC>
 struct Geo {
   static constexpr int UNITS = (PREC == 1) ? 16 : 32;
-  static constexpr int KM_STRIDE = UNITS + 4;          // dwords per row of a K-major image: slot stride 5 / 9, both odd
+  // dwords per row of a K-major image.  fp32: 32 + 4 pad (slot stride 9, odd: ds_read_b128 fragments conflict free).
+  // bf16: 16, UNPADDED, with the row's four 16-byte chunks XOR-swizzled by (row >> 2) & 3 (km_chunk): the 8-byte
+  // staging stores of a 16-lane group then cover 32 consecutive dwords (the padded image made them 2-way conflicted:
+  // a third of the LDS cycles, profiles/r04_pmc_gemm), and the 16 rows of a ds_read_b128 group still hit 16 distinct
+  // 16-byte bank groups (rows with equal r & 3 differ in (r >> 2) & 3).
+  static constexpr int KM_STRIDE = (PREC == 1) ? UNITS : UNITS + 4;
   static constexpr int IMG_DWORDS = (128 * KM_STRIDE > UNITS * MN_STRIDE) ? 128 * KM_STRIDE : UNITS * MN_STRIDE;
   static constexpr int NS = UNITS / 8;                 // fragment sub-steps per k-step
 };
@@ -197,8 +200,9 @@ __device__ __forceinline__ void store_kmajor(const Staged<PREC>& s, uint32_t* im
       uint32_t h0, l0, h1, l1;
       split2(v[0], v[1], h0, l0);
       split2(v[2], v[3], h1, l1);
-      *(u32x2*)(img + r * Geo<PREC>::KM_STRIDE + 2 * kq) = u32x2{h0, h1};
-      *(u32x2*)(img + Geo<PREC>::IMG_DWORDS + r * Geo<PREC>::KM_STRIDE + 2 * kq) = u32x2{l0, l1};
+      const int pos = r * Geo<PREC>::KM_STRIDE + ((((kq >> 1) ^ ((r >> 2) & 3)) << 2) | ((kq & 1) << 1));
+      *(u32x2*)(img + pos) = u32x2{h0, h1};
+      *(u32x2*)(img + Geo<PREC>::IMG_DWORDS + pos) = u32x2{l0, l1};
     } else {                               // (stored as dwords, the type every fragment read uses)
       *(u32x4*)(img + r * Geo<PREC>::KM_STRIDE + 4 * kq) = __builtin_bit_cast(u32x4, v);
     }
@@ -234,7 +238,11 @@ __device__ __forceinline__ void store_mnmajor(const Staged<PREC>& s, uint32_t* i
 // a lane's fragment of row `row` (0..127 inside the tile) for sub-step s: units 8s + 4h + {0..3}
 template <int PREC, int LAY>
 __device__ __forceinline__ u32x4 frag(const uint32_t* img, int row, int s, int h) {
-  if (LAY == LAY_K) return *(const u32x4*)(img + row * Geo<PREC>::KM_STRIDE + 8 * s + 4 * h);
+  if (LAY == LAY_K) {
+    if (PREC == PREC_BF16X3)      // chunk 2s + h of the row, at its swizzled position
+      return *(const u32x4*)(img + row * Geo<PREC>::KM_STRIDE + (((2 * s + h) ^ ((row >> 2) & 3)) << 2));
+    return *(const u32x4*)(img + row * Geo<PREC>::KM_STRIDE + 8 * s + 4 * h);
+  }
   u32x4 f;
   const uint32_t* p = img + (8 * s + 4 * h) * MN_STRIDE + row;
 #pragma unroll
@@ -640,8 +648,11 @@ void launch_ws(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStre
   else hipLaunchKernelGGL((gemm_mfma_ws_kernel<PREC, LAY_MN, LAY_MN>), grid, dim3(WS_THREADS), 0, st, g);
 }
 
-int g_gemm_variant = 1;      // 0: every wave does every job (round 4); 1 / 2: wave-specialised producer / consumer
-                             // workgroups, one / two of them per CU
+// 0 (default): every wave does every job (round 4); 1 / 2: wave-specialised producer / consumer workgroups, one /
+// two of them per CU.  Measured (profiles/r05_kbench_gemm_variants.log): two wave-specialised workgroups per CU tie
+// with the default within +-10 % on every shape, one per CU is 15 - 60 % slower -- the kernel is bound by the
+// per-k-step LDS + split work that both forms share, not by the overlap structure.  Kept as the A/B it is.
+int g_gemm_variant = 0;
 
 template <int PREC>
 void launch(const GemmArgs& g, int a_layout, int b_layout, dim3 grid, hipStream_t st) {
@@ -680,7 +691,7 @@ extern "C" {
 
 int vidar_gemm_set_variant(int variant) {
   const int prev = g_gemm_variant;
-  g_gemm_variant = (variant < 0 || variant > 2) ? 1 : variant;
+  g_gemm_variant = (variant < 0 || variant > 2) ? 0 : variant;
   return prev;
 }
 
