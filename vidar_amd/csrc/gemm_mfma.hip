@@ -360,7 +360,8 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, 
 // the descriptors end at the matrix' last element, so rows past M read as 0 (a garbage load could only feed a row that
 // is never stored anyway) and their stores are dropped by the hardware's range check -- and, independently of it,
 // by an explicit row predicate; the column test n < N is made once per column tile.
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, const Tile& T, int tid) {
+template <bool RAGGED_M>
+__device__ __forceinline__ void epilogue_impl(const f32x16 (&acc)[2][2], const GemmArgs& g, const Tile& T, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
@@ -409,15 +410,22 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmAr
             y = y * sc[r] + sh[r] + rs[r];
             if (g.relu && !(y > 0.0f)) y = 0.0f;
           }
-          // rows >= M: an explicit predicate on top of the descriptor's range check (the row part of the offset is a
-          // scalar offset, which the hardware only checks through the gfx9 rule num_records - soffset)
-          if (row < mleft)
+          // rows >= M (only a tile of the last tile row has any: RAGGED_M): an explicit predicate on top of the
+          // descriptor's range check (the row part of the offset is a scalar offset, which the hardware only checks
+          // through the gfx9 rule num_records - soffset).  Full tiles keep the bare store burst -- the predicate's
+          // exec-mask juggling around each of the 64 stores cost the fused conv3 epilogue 19 % (528 -> 629 us).
+          if (!RAGGED_M || row < mleft)
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, y), rsC, voC,
                                                     (uint32_t)((row * (uint32_t)ldc + 32 * j) * 4), 0);
         }
       }
     }
   }
+}
+
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, const Tile& T, int tid) {
+  if (g.M - T.m0 >= BM) epilogue_impl<false>(acc, g, T, tid);       // workgroup-uniform
+  else epilogue_impl<true>(acc, g, T, tid);
 }
 
 // Persistent workgroups: the grid is (at most) one residency of the chip, and a workgroup walks tiles t = blockIdx,
