@@ -44,17 +44,18 @@ def test_pmc_traffic_is_backed_by_committed_profiles():
     sys.path.insert(0, str(ROOT))
     import bench
     nbytes, src = bench.pmc_traffic("msda_bwd[L=4,P=8]")
-    assert nbytes and nbytes > 8.7e8                        # at least the algorithmic bytes
-    # counted on the access pattern the in-model kernel time belongs to: spatially coherent queries (round 4)
-    assert "r04_pmc_msda_sca_coherent" in src and "coherent" in src and "calibration" in src
+    assert nbytes and nbytes > 7.5e8                        # at least the algorithmic bytes (756 MB at 7 680 queries / camera)
+    # counted on the access pattern AND at the size the in-model kernel time belongs to: spatially coherent queries
+    # (round 4), 7 680 padded visible queries per camera (round 5; the SURVEY shape has 10^4)
+    pmc_dir = "r05_pmc_msda_sca_coherent_nq7680"
+    assert pmc_dir in src and "coherent" in src and "calibration" in src and "Nq=7680" in src
     for f in ("pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv"):
-        assert (ROOT / "profiles" / "r04_pmc_msda_sca_coherent" / f).exists()
+        assert (ROOT / "profiles" / pmc_dir / f).exists()
     assert bench.pmc_traffic("no such kernel") == (None, None)
     # the json is reproducible from the csv files
-    r = subprocess.run([sys.executable, str(ROOT / "tools" / "make_pmc_traffic.py"), "profiles/r04_pmc_msda_sca_coherent",
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "make_pmc_traffic.py"), "profiles/" + pmc_dir,
                         "profiles/r03_pmc_FETCH_SIZE_calibration.csv", "profiles/r03_pmc_WRITE_SIZE_calibration.csv",
-                        "spatially coherent queries (8 level-0 pixels between neighbours), head-major item order",
-                        "msda_sca_coherent"],
+                        "spatially coherent queries, head-major item order", "msda_sca_coherent", "7680"],
                        capture_output=True, text=True, cwd=ROOT, timeout=60)
     made = json.loads(r.stdout)
     have = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())

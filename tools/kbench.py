@@ -185,8 +185,10 @@ def bench_msda_sca_coherent(which):
     from vidar_amd.synthetic import msda_operands_coherent
     from vidar_amd.plugin.modules.multi_scale_deformable_attn_function import _msda_backward, _msda_forward
     fpn = [(116, 200), (58, 100), (29, 50), (15, 25)]
-    value, sh, lsi, loc, w = msda_operands_coherent(0, 6, fpn, 10000, P=8, px=8.0, device="cuda")
-    go = torch.randn(6, 10000, 256, device="cuda")
+    import os
+    nq = int(os.environ.get("VIDAR_KBENCH_NQ", "10000"))      # 7680 = the padded visible-query count of the bench's step
+    value, sh, lsi, loc, w = msda_operands_coherent(0, 6, fpn, nq, P=8, px=8.0, device="cuda")
+    go = torch.randn(6, nq, 256, device="cuda")
     report("msda_fwd SCA coherent", timeit(lambda: _msda_forward(value, sh, lsi, loc, w), warm=1, it=3))
     report("msda_bwd SCA coherent binned=True", timeit(lambda: _msda_backward(value, sh, lsi, loc, w, go, binned=True), warm=1, it=3))
 

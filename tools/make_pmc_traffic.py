@@ -19,7 +19,7 @@ def table(path):
     return {(r["kernel"], r["counter"]): float(r["mean_value"]) for r in csv.DictReader(open(path))}
 
 
-def main(pmc_dir, fetch_cal, write_cal, pattern="random reference points", target="msda_sca"):
+def main(pmc_dir, fetch_cal, write_cal, pattern="random reference points", target="msda_sca", nq="10000"):
     fc, wc = table(fetch_cal), table(write_cal)
     nlines = (1 << 30) // 128
     fetch_factor = ((1 << 30) + 4 * nlines) / (fc[("calib_gather128", "FETCH_SIZE")] * 1024)
@@ -27,13 +27,13 @@ def main(pmc_dir, fetch_cal, write_cal, pattern="random reference points", targe
     d = Path(pmc_dir)
     f, w = table(d / "pmc_FETCH_SIZE.csv"), table(d / "pmc_WRITE_SIZE.csv")
     kb = lambda t, k, c: t.get((k, c), 0.0) * 1024
-    B, Nv, Nq, H, C, L, P = 6, 30825, 10000, 8, 32, 4, 8
+    B, Nv, Nq, H, C, L, P = 6, 30825, int(nq), 8, 32, 4, 8
     fwd_alg = 4 * (B * Nv * H * C + B * Nq * H * L * P * 3 + B * Nq * H * C)
     bwd_alg = fwd_alg + 4 * (B * Nq * H * C + B * Nv * H * C + B * Nq * H * L * P * 3)
     src = (f"{d}/pmc_{{FETCH,WRITE}}_SIZE.csv (tools/pmc_pass.sh: rocprofv3 --pmc in separate passes over `tools/kbench.py "
-           f"{target}`, SCA shape B=6 Nq=10^4 L=4 P=8, {pattern}); FETCH_SIZE x {fetch_factor:.3f} and WRITE_SIZE x "
+           f"{target}`, SCA shape B=6 Nq={Nq} L=4 P=8, {pattern}); FETCH_SIZE x {fetch_factor:.3f} and WRITE_SIZE x "
            f"{write_factor:.3f} from the calibration on a known byte count ({fetch_cal}, {write_cal})")
-    out = {"calibration": {"fetch_factor": round(fetch_factor, 4), "write_factor": round(write_factor, 4),
+    out = {"queries_per_camera": Nq, "calibration": {"fetch_factor": round(fetch_factor, 4), "write_factor": round(write_factor, 4),
                            "pattern": "random 128-byte lines, 8 lanes x float4, 1 GiB buffer, every line once",
                            "source": f"{fetch_cal}, {write_cal}, tools/micro/fetch_calib.hip"}}
     bwd_kernels = ["msda_bin_kernel<false>", "msda_bin_scan_kernel", "msda_bin_kernel<true>", "msda_bwd_tile_kernel",
@@ -52,4 +52,4 @@ def main(pmc_dir, fetch_cal, write_cal, pattern="random reference points", targe
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:6])
+    main(*sys.argv[1:7])
