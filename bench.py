@@ -527,6 +527,8 @@ def ddp_info(ddp, world):
     """what the gradient all-reduce moves per step (RCCL over xGMI): DDP's own bucket accounting.  With
     find_unused_parameters=False torch starts with ONE bucket and rebuilds the buckets after the first step in
     the order gradients became ready -- `rebuilt_bucket_bytes` is what overlaps with backward from step 2 on."""
+    if hasattr(ddp, "logging_data"):                                 # vidar_amd.train.FlatAllReduce (the default)
+        return dict(ddp.logging_data(), backend=dist.get_backend(), world_size=world)
     if not hasattr(ddp, "_get_ddp_logging_data"):
         return None
     try:

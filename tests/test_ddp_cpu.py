@@ -14,9 +14,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VIDAR_DDP=mode)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -31,7 +31,7 @@ def _worker(rank, world, port, out):
     cfg, batch = _small_batch("vidar_1_8_nusc_1future", seed=10 + rank)   # different sample per rank
     model = T.build_model(cfg).train()
     ddp = T.wrap_ddp(model, l)
-    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel if mode == "torch" else T.FlatAllReduce)
     opt = T.build_optimizer(model)
     with cpu_ops.patched():
         loss, _ = T.train_step(ddp, opt, batch)
@@ -39,16 +39,25 @@ def _worker(rank, world, port, out):
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
-    out[rank] = (float(loss), float((gathered[0] - gathered[1]).abs().max()))
+    out[rank] = (float(loss), float((gathered[0] - gathered[1]).abs().max()), flat[::997].double().sum().item())
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_gloo():
+def _run(mode):
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
     assert set(out.keys()) == {0, 1}
     assert out[0][0] != out[1][0], "ranks must see different samples"
-    assert out[0][1] == 0.0, "parameters diverged across ranks after the DDP step"
+    assert out[0][1] == 0.0, "parameters diverged across ranks after the data-parallel step"
+    return out[0][2]
+
+
+def test_ddp_two_ranks_gloo():
+    """the default gradient exchange (one flat all-reduce after backward, train.FlatAllReduce) and torch's
+    DistributedDataParallel (VIDAR_DDP=torch): replicas stay identical, and both produce the same update"""
+    a = _run("flat")
+    b = _run("torch")
+    assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (a, b)

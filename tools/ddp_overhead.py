@@ -3,10 +3,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
         tools/ddp_overhead.py [--steps 10]
 
-Times the same training step (same weights, same batch) four ways on ONE rank of a real RCCL group:
+Times the same training step (same weights, same batch) five ways on ONE rank of a real RCCL group:
   plain      the bare module (what `bench.py --gpus 1` times)
-  ddp        DistributedDataParallel as vidar_amd.train.wrap_ddp builds it
-  no_sync    the same wrapper inside `no_sync()`: every autograd hook still runs, no bucket is reduced
+  flat       vidar_amd.train.FlatAllReduce: one flat all-reduce after backward (the default of wrap_ddp)
+  ddp        torch's DistributedDataParallel as wrap_ddp builds it under VIDAR_DDP=torch
+  no_sync    that wrapper inside `no_sync()`: every autograd hook still runs, no bucket is reduced
   collective the bucket traffic alone: dist.all_reduce of tensors of the rebuilt bucket sizes, no model
 so that `ddp - no_sync` = what the all-reduce launches cost and `no_sync - plain` = the reducer's host-side
 bookkeeping (one autograd hook per parameter) on a step whose backward is launch-bound in places."""
@@ -66,11 +67,16 @@ def main():
         torch.cuda.synchronize()
         out[tag] = round((time.perf_counter() - t0) / args.steps * 1e3, 2)
         info = bench.ddp_info(m, world) if hasattr(m, "_get_ddp_logging_data") else None
+        if hasattr(m, "logging_data"):
+            out["flat_allreduce_bytes"] = m.logging_data()["allreduce_bytes_per_step"]
         del m, model, opt, batch
         torch.cuda.empty_cache()
         return info
 
     run("plain_ms", lambda mod: mod)
+    os.environ["VIDAR_DDP"] = "flat"
+    run("flat_allreduce_ms", lambda mod: T.wrap_ddp(mod, local))
+    os.environ["VIDAR_DDP"] = "torch"
     info = run("ddp_ms", lambda mod: T.wrap_ddp(mod, local))
     run("ddp_no_sync_ms", lambda mod: T.wrap_ddp(mod, local), ctx=lambda m: m.no_sync())
     sizes = (info or {}).get("bucket_bytes") or [106 << 20, 144 << 20]

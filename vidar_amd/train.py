@@ -77,11 +77,58 @@ def init_distributed():
     return rank, local, world
 
 
+class FlatAllReduce(torch.nn.Module):
+    """Data parallelism with ONE gradient all-reduce per step on a flat buffer, after backward.
+
+    What torch's DistributedDataParallel costs on this step was measured on one rank of a real RCCL group
+    (tools/ddp_overhead.py, profiles/r05_ddp_overhead_1rank.json): +5.9 ms per step, of which the reducer's autograd
+    hooks are 0.6 ms and the collective itself 0.09 ms -- the rest is the per-parameter bucket traffic of a reducer that
+    overlaps the all-reduce with backward (334 gradients copied into bucket views one launch at a time inside a
+    backward pass that is GPU-bound), i.e. the overlap machinery costs more than the 250 MB all-reduce it hides (~2 ms
+    over 8 x xGMI, < 1 % of a 350 ms step).  So: no hooks, no buckets -- after backward the gradients are gathered into
+    one flat buffer (one batched copy), pre-divided by the world size, all-reduced (RCCL over xGMI) and handed back to
+    the parameters as views of that buffer.  Same result as DDP's averaged gradients (sum of g / world in rank order
+    is what both compute).  `VIDAR_DDP=torch` selects torch's DistributedDataParallel instead."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        self.world = dist.get_world_size()
+        self.last_bytes = 0
+        with torch.no_grad():                      # every rank starts from rank 0's weights and buffers (DDP does the same)
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def reduce_gradients(self):
+        params = [p for p in self.module.parameters() if p.grad is not None]
+        if not params:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        if self.world > 1:
+            flat.div_(self.world)
+        dist.all_reduce(flat)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad = flat[off:off + n].view_as(p)
+            off += n
+        self.last_bytes = flat.numel() * flat.element_size()
+
+    def logging_data(self):
+        return {"mode": "flat all-reduce after backward (vidar_amd.train.FlatAllReduce)", "buckets": 1,
+                "bucket_bytes": [self.last_bytes], "allreduce_bytes_per_step": self.last_bytes}
+
+
 def wrap_ddp(model, local_rank, bucket_cap_mb=100):
     if not (dist.is_available() and dist.is_initialized()):
         return model
     if dist.get_world_size() == 1 and os.environ.get("VIDAR_FORCE_DDP") != "1":
         return model
+    if os.environ.get("VIDAR_DDP", "flat") != "torch":
+        return FlatAllReduce(model)
     kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
               find_unused_parameters=False)
     if torch.cuda.is_available():
@@ -90,11 +137,13 @@ def wrap_ddp(model, local_rank, bucket_cap_mb=100):
 
 
 def train_step(model, optimizer, batch, max_norm=35.0):
-    """forward -> sum of the loss dict -> backward (DDP all-reduce) -> clip -> AdamW step."""
+    """forward -> sum of the loss dict -> backward -> gradient all-reduce (flat, or DDP's buckets) -> clip -> AdamW step."""
     losses = model(return_loss=True, **batch)
     total = sum(v for v in losses.values())
     optimizer.zero_grad(set_to_none=True)
     total.backward()
+    if isinstance(model, FlatAllReduce):
+        model.reduce_gradients()
     params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
     torch.nn.utils.clip_grad_norm_(params, max_norm)
     optimizer.step()
