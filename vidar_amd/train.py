@@ -103,10 +103,13 @@ class FlatAllReduce(torch.nn.Module):
         return self.module(*args, **kwargs)
 
     def reduce_gradients(self):
-        params = [p for p in self.module.parameters() if p.grad is not None]
+        # every rank must contribute the same layout: all trainable parameters in module order, a parameter that got
+        # no gradient on this rank contributes zeros (the hot path gives every trainable parameter a gradient every
+        # step, tests/test_ddp_cpu.py -- this only keeps an unusual batch from dead-locking the collective)
+        params = [p for p in self.module.parameters() if p.requires_grad]
         if not params:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
         if self.world > 1:
             flat.div_(self.world)
         dist.all_reduce(flat)
