@@ -360,6 +360,10 @@ int vidar_ray_argmax_f32(const float* sigma, const float* origin, const float* p
  *   reduce = 1: ONE output C = act(sum_z A[z]*B[z] ...) -- the batch items are summed and K is additionally split
  *     (vidar_gemm_splits) so that a weight gradient fills the chip; partial products go to `workspace`
  *     (vidar_gemm_workspace_bytes) as fp32 slabs and are summed in a fixed order: deterministic, no atomics.
+ *   a_rowsum (reduce = 1 and an MN-major A only; else NULL): a_rowsum[m] = sum_z sum_k A[z][m, k] written next to C --
+ *     with A = grad_out^T this is the bias gradient of the nn.Linear whose weight gradient the call computes
+ *     (autograd's grad_out.sum(0)): the tile-column-0 workgroups add up the A values they stage anyway, partial rows
+ *     go behind the slabs and are reduced in the same fixed order.  Deterministic, and no second pass over grad_out.
  * ------------------------------------------------------------------------- */
 #define VIDAR_GEMM_F32 0
 #define VIDAR_GEMM_BF16X3 1
@@ -368,8 +372,8 @@ int vidar_ray_argmax_f32(const float* sigma, const float* origin, const float* p
 int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, int64_t ldb, int b_layout, float* C,
                    int64_t ldc, int M, int N, int K, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                    const float* scale, const float* shift, int vec_axis, const float* residual, int64_t ldr,
-                   int64_t strideR, int relu, int precision, int reduce, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   int64_t strideR, int relu, int precision, int reduce, float* a_rowsum, void* workspace,
+                   size_t workspace_bytes, void* stream);
 int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce);
 size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce);
 /* A/B switch of the kernel's structure: 0 (default) = every wave does every job; 1 / 2 = wave-specialised workgroups

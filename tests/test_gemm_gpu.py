@@ -120,6 +120,27 @@ def test_split_k_weight_gradient_with_ragged_sizes(precision, rows, N, K):
     ref = g.double().t() @ x.double()
     assert normwise(gw, ref) <= (3e-6 if precision == G.F32 else 8e-5)
     assert torch.equal(gw, G.linear_grad_weight(g, x, precision))
+    # the bias gradient rides along (a_rowsum): same weight gradient bit for bit, g.sum(0) in a fixed order
+    gw2, gb = G.linear_grad_weight(g, x, precision, with_bias=True)
+    assert torch.equal(gw2, gw)
+    assert normwise(gb, g.double().sum(0)) <= 2e-6          # exact fp32 adds in both modes (no split on this path)
+    gw3, gb3 = G.linear_grad_weight(g, x, precision, with_bias=True)
+    assert torch.equal(gb, gb3) and torch.equal(gw3, gw), "weight and bias gradient must be deterministic"
+
+
+@pytest.mark.parametrize("precision", [G.F32, G.BF16X3])
+def test_bias_gradient_rides_along_at_the_baseline_shapes(precision):
+    """grad_out [184 950, 256] (SpatialCrossAttention value projection) and [40 000, 512] (FFN): the row sums written next
+    to the weight gradient equal grad_out.sum(0), including a row-sliced (strided) grad_out and a single-tile product"""
+    for rows, N, K in ((184950, 256, 256), (40000, 512, 256), (300, 128, 256)):
+        g, x = rnd(rows, N, seed=31), rnd(rows, K, seed=32)
+        gw, gb = G.linear_grad_weight(g, x, precision, with_bias=True)
+        assert normwise(gb, g.double().sum(0)) <= 3e-6
+        assert normwise(gw, g.double().t() @ x.double()) <= (3e-6 if precision == G.F32 else 8e-5)
+    wide = rnd(5000, 300, seed=33)
+    g = wide[:, 20:150]                                       # leading dimension 300 > 130 columns
+    gw, gb = G.linear_grad_weight(g, rnd(5000, 64, seed=34), precision, with_bias=True)
+    assert normwise(gb, g.double().sum(0)) <= 3e-6
 
 
 @pytest.mark.parametrize("M,K,N", [(184950, 256, 256), (80000, 256, 256), (40000, 512, 128)])

@@ -88,6 +88,11 @@ struct GemmArgs {
   int relu;
   int tiles_m, tiles_n, m_fastest;
   int total;       // tiles_m * tiles_n * (batch * splits)
+  // a_rowsum != nullptr (reduced products with an MN-major A only): out[m] = sum_z sum_k A[z][m, k] -- the bias gradient of
+  // an nn.Linear rides along with its weight gradient (A = grad_out^T).  The workgroups of tile column 0 add the A values
+  // they stage anyway and write one partial row per slab behind the slabs; the slab reduction sums them in z order.
+  float* a_rowsum;
+  float* rowsum_ws;     // [Z][M] partial rows (inside the caller's workspace)
 };
 
 // ---- staging: 16 floats per operand per thread ------------------------------------------------------------------------
@@ -301,15 +306,25 @@ __device__ __forceinline__ void fetch(Staged<PREC>& sa, Staged<PREC>& sb, const 
 }
 
 // the k loop of one tile.  On entry the staging registers hold (or are about to receive) the tile's first k-step.
+// sum over the staged k of a thread's A values, per row of its row quad (MN-major staging: every float4 of a thread is
+// the same four consecutive rows at another k; rows / k outside the matrix were read as 0)
+template <int PREC>
+__device__ __forceinline__ void add_rowsum(f32x4& rs, const Staged<PREC>& sa) {
+#pragma unroll
+  for (int i = 0; i < Staged<PREC>::CH * 2; ++i) rs += sa.v[i >> 1][i & 1];
+}
+
 template <int PREC, int ALAY, int BLAY>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], Staged<PREC>& sa, Staged<PREC>& sb, const GemmArgs& g,
-                                         const Tile& T, uint32_t* imgA, uint32_t* imgB, int tid, uint32_t voa, uint32_t vob) {
+                                         const Tile& T, uint32_t* imgA, uint32_t* imgB, int tid, uint32_t voa, uint32_t vob,
+                                         f32x4& rowsum, bool want_rowsum) {
   constexpr int IMGS = (PREC == PREC_BF16X3) ? 2 : 1;
   constexpr int IMG_DWORDS = Geo<PREC>::IMG_DWORDS;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
   const int l31 = lane & 31, h = lane >> 5;
   for (int k0 = T.kbeg; k0 < T.kend; k0 += BK) {
+    if (ALAY == LAY_MN && want_rowsum) add_rowsum<PREC>(rowsum, sa);
     if (ALAY == LAY_K) store_kmajor<PREC>(sa, imgA, tid); else store_mnmajor<PREC>(sa, imgA, tid);
     if (BLAY == LAY_K) store_kmajor<PREC>(sb, imgB, tid); else store_mnmajor<PREC>(sb, imgB, tid);
     __syncthreads();
@@ -454,7 +469,24 @@ __global__ __launch_bounds__(THREADS, 3) void gemm_mfma_kernel(GemmArgs g) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    mainloop<PREC, ALAY, BLAY>(acc, sa, sb, g, cur, imgA, imgB, tid, voa, vob);
+    f32x4 rowsum = {0.f, 0.f, 0.f, 0.f};
+    const bool want_rowsum = ALAY == LAY_MN && g.a_rowsum != nullptr && cur.n0 == 0;     // workgroup-uniform
+    mainloop<PREC, ALAY, BLAY>(acc, sa, sb, g, cur, imgA, imgB, tid, voa, vob, rowsum, want_rowsum);
+    if (want_rowsum) {
+      // the 8 threads that staged the same row quad (tid & 31, both modes) combine through LDS -- free after the k loop's
+      // last barrier -- in a fixed order; rows m0 .. m0 + 127 of slab z
+      float* red = reinterpret_cast<float*>(lds);
+      const int quad = tid & 31, part = tid >> 5;
+      *(f32x4*)(red + (part * 32 + quad) * 4) = rowsum;
+      __syncthreads();
+      if (tid < BM) {
+        float sum = 0.f;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) sum += red[(p8 * 32 + (tid >> 2)) * 4 + (tid & 3)];
+        if (cur.m0 + tid < g.M) g.rowsum_ws[(int64_t)cur.z * g.M + cur.m0 + tid] = sum;
+      }
+      __syncthreads();
+    }
     const int tn = t + (int)gridDim.x;
     const bool more = tn < g.total;
     if (more) {        // only the tile NUMBER survives the epilogue (registers): the next tile is decoded twice
@@ -618,6 +650,12 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_mfma_ws_kernel(GemmArgs g)
 // z-group order -- the order of the additions is fixed, the result is deterministic.
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __restrict__ ws, int Z, GemmArgs g) {
   __shared__ f32x4 part[4][64];
+  if (g.a_rowsum != nullptr && blockIdx.x == gridDim.x - 1)      // the bias-gradient rows: z order, one thread per row
+    for (int m = threadIdx.x; m < g.M; m += 256) {
+      float a = 0.f;
+      for (int z = 0; z < Z; ++z) a += g.rowsum_ws[(int64_t)z * g.M + m];
+      g.a_rowsum[m] = a;
+    }
   const int64_t total = (int64_t)g.M * g.N;                  // a multiple of 4 is NOT required: the tail is scalar
   const int64_t quads = total >> 2;
   const int col = threadIdx.x & 63, zg = threadIdx.x >> 6;
@@ -711,16 +749,18 @@ int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce)
 size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce) {
   if (!reduce) return 0;
   const int s = vidar_gemm_splits(M, N, K, batch, precision, reduce);
-  if (batch * s == 1) return 0;
-  return (size_t)batch * s * M * N * sizeof(float);
+  // Z slabs of [M, N] + Z partial rows of [M] (the optional row sums of A); a single-slab product without row sums
+  // needs none, but the query cannot know about the row sums: it always answers for them
+  return (size_t)batch * s * ((size_t)M * N + M) * sizeof(float);
 }
 
 int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, int64_t ldb, int b_layout, float* C,
                    int64_t ldc, int M, int N, int K, int batch, int64_t strideA, int64_t strideB, int64_t strideC,
                    const float* scale, const float* shift, int vec_axis, const float* residual, int64_t ldr,
-                   int64_t strideR, int relu, int precision, int reduce, void* workspace, size_t workspace_bytes,
-                   void* stream) {
+                   int64_t strideR, int relu, int precision, int reduce, float* a_rowsum, void* workspace,
+                   size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
+  if (a_rowsum != nullptr && !(reduce && a_layout == LAY_MN)) return VIDAR_ERR_BAD_ARG;
   if (A == nullptr || B == nullptr || C == nullptr || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return VIDAR_ERR_BAD_ARG;
   if ((a_layout != LAY_K && a_layout != LAY_MN) || (b_layout != LAY_K && b_layout != LAY_MN)) return VIDAR_ERR_BAD_ARG;
   if (precision != PREC_F32 && precision != PREC_BF16X3) return VIDAR_ERR_BAD_ARG;
@@ -745,7 +785,9 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   g.splits = reduce ? pick_splits(M, N, K, batch, bk) : 1;
   g.k_chunk = ((K + g.splits - 1) / g.splits + bk - 1) / bk * bk;
   const int Z = batch * g.splits;
-  g.slabs = (reduce && Z > 1) ? 1 : 0;
+  g.slabs = (reduce && (Z > 1 || a_rowsum != nullptr)) ? 1 : 0;
+  g.a_rowsum = a_rowsum;
+  g.rowsum_ws = nullptr;
   if ((int64_t)g.tiles_m * g.tiles_n * Z > 0x3fffffff) return VIDAR_ERR_BAD_ARG;
   g.total = g.tiles_m * g.tiles_n * Z;
   // a reduced product writes slabs and the reduction kernel applies the epilogue on [M, N] of ONE output: batch and
@@ -753,14 +795,17 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
   if (reduce && (strideC != 0 || strideR != 0) && batch > 1) return VIDAR_ERR_BAD_ARG;
   GemmArgs k = g;
   if (g.slabs) {
-    if (workspace == nullptr || workspace_bytes < (size_t)Z * M * N * sizeof(float)) return VIDAR_ERR_BAD_ARG;
+    const size_t need = (size_t)Z * ((size_t)M * N + (a_rowsum ? M : 0)) * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need) return VIDAR_ERR_BAD_ARG;
     k.C = (float*)workspace;
+    g.rowsum_ws = a_rowsum ? (float*)workspace + (size_t)Z * M * N : nullptr;
+    k.rowsum_ws = g.rowsum_ws;
   }
   k.total = g.tiles_m * g.tiles_n * Z;
   // one residency of the chip: 3 workgroups per CU (launch bounds: 3 waves per SIMD), a multiple of 8 so that t & 7
   // stays the workgroup's XCD for every tile it walks.  (Measured against one workgroup per tile and against fetching
   // the next tile after the epilogue: within noise of each other on MI355X, profiles/r04_kbench_gemm_*.)
-  if (g_gemm_variant >= 1) {
+  if (g_gemm_variant >= 1 && a_rowsum == nullptr) {
     // one (two) 512-thread workgroup(s) per CU (a multiple of 8 keeps t & 7 = the XCD for every tile a workgroup walks)
     const int resident = num_cus() * g_gemm_variant / 8 * 8;
     dim3 grid(k.total > resident ? resident : k.total);

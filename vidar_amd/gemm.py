@@ -107,7 +107,7 @@ def _operand(t, layout, contraction, what):
 
 
 def gemm_raw(A, lda, a_layout, B, ldb, b_layout, C, ldc, M, N, K, *, batch=1, sA=0, sB=0, sC=0, scale=None, shift=None,
-             vec_axis=0, residual=None, ldr=0, sR=0, relu=False, precision=F32, reduce=False, name="gemm"):
+             vec_axis=0, residual=None, ldr=0, sR=0, relu=False, precision=F32, reduce=False, a_rowsum=None, name="gemm"):
     """one call of vidar_gemm_f32 on torch tensors (pointers are taken as they are: the caller states the geometry)"""
     L = lib()
     ws, nbytes = None, 0
@@ -123,7 +123,8 @@ def gemm_raw(A, lda, a_layout, B, ldb, b_layout, C, ldc, M, N, K, *, batch=1, sA
                                ptr(C), ctypes.c_int64(ldc), int(M), int(N), int(K), int(batch), ctypes.c_int64(sA),
                                ctypes.c_int64(sB), ctypes.c_int64(sC), ptr(scale), ptr(shift), int(vec_axis),
                                ptr(residual), ctypes.c_int64(ldr), ctypes.c_int64(sR), int(bool(relu)), int(precision),
-                               int(bool(reduce)), ptr(ws), ctypes.c_size_t(nbytes), stream_of(C)), "vidar_gemm_f32")
+                               int(bool(reduce)), ptr(a_rowsum), ptr(ws), ctypes.c_size_t(nbytes), stream_of(C)),
+              "vidar_gemm_f32")
     return C
 
 
@@ -153,16 +154,20 @@ def linear_grad_input(g2, weight, precision=F32):
                     name="gemm_linear_dx")
 
 
-def linear_grad_weight(g2, x2, precision=F32):
-    """g2 [M,N]^T @ x2 [M,K] -> [N,K]  (the contraction runs over the rows: split over K', slabs summed in order)"""
+def linear_grad_weight(g2, x2, precision=F32, with_bias=False):
+    """g2 [M,N]^T @ x2 [M,K] -> [N,K]  (the contraction runs over the rows: split over K', slabs summed in order).
+    with_bias: also the bias gradient g2.sum(0) [N], from the same pass over g2 (`a_rowsum` of vidar_gemm_f32: summed in a
+    fixed order, unlike the atomic column-sum kernel) -> (grad_weight, grad_bias)"""
     M, N = g2.shape
     K = x2.shape[1]
     g2 = _operand(g2, MN_MAJOR, M, "grad_out"); x2 = _operand(x2, MN_MAJOR, M, "x")
     gw = torch.empty((N, K), dtype=torch.float32, device=g2.device)
+    gb = torch.empty(N, dtype=torch.float32, device=g2.device) if with_bias else None
     if M == 0:
-        return gw.zero_()
-    return gemm_raw(g2, g2.stride(0), MN_MAJOR, x2, x2.stride(0), MN_MAJOR, gw, K, N, K, M, precision=precision,
-                    reduce=True, name="gemm_linear_dw")
+        return (gw.zero_(), gb.zero_()) if with_bias else gw.zero_()
+    gemm_raw(g2, g2.stride(0), MN_MAJOR, x2, x2.stride(0), MN_MAJOR, gw, K, N, K, M, precision=precision,
+             reduce=True, a_rowsum=gb, name="gemm_linear_dw")
+    return (gw, gb) if with_bias else gw
 
 
 def linear_grad_weight_ok(g2, x2) -> bool:
@@ -200,8 +205,14 @@ class MfmaLinear(torch.autograd.Function):
         if relu:
             g2 = g2 * (y > 0)
         gx = linear_grad_input(g2, weight, precision) if ctx.needs_input_grad[0] else None
-        gw = linear_grad_weight(g2, x2, precision) if ctx.needs_input_grad[1] else None
-        gb = _colsum(g2) if (has_bias and ctx.needs_input_grad[2]) else None
+        want_b = has_bias and ctx.needs_input_grad[2]
+        gw = gb = None
+        if ctx.needs_input_grad[1]:                       # the bias gradient rides along with the weight gradient
+            gw = linear_grad_weight(g2, x2, precision, with_bias=want_b)
+            if want_b:
+                gw, gb = gw
+        elif want_b:
+            gb = _colsum(g2)
         return gx, gw, gb, None, None
 
 

@@ -78,7 +78,12 @@ class _LinearColsum(torch.autograd.Function):
             # (operands the kernel cannot read in place -- a transposed / expanded view, a leading dimension beyond its
             #  addressing range -- take the library product like every other mode)
             own = _gemm.mode() == "auto" and _gemm.linear_grad_weight_ok(g2, x2)
-            gw = _gemm.linear_grad_weight(g2, x2, _gemm.F32) if own else (x2.t() @ g2).t()
+            if own:
+                # ... and the bias gradient with it: summed by the same kernel from the grad_out tiles it stages anyway, in
+                # a fixed order (deterministic like torch's sum(0); the atomic column-sum kernel below is not)
+                gw, gb = _gemm.linear_grad_weight(g2, x2, _gemm.F32, with_bias=True)
+                return gx, gw, gb
+            gw = (x2.t() @ g2).t()
         gb = torch.empty(g2.shape[1], dtype=torch.float32, device=g2.device)
         check(lib().vidar_colsum_f32(ptr(g2), ptr(gb), ctypes.c_int64(g2.shape[0]), int(g2.shape[1]), stream_of(g2)),
               "colsum")
@@ -87,9 +92,9 @@ class _LinearColsum(torch.autograd.Function):
 
 class Linear(nn.Linear):
     """nn.Linear (same parameters / state-dict keys) for the modules on the hot path: on CUDA fp32 tensors the bias
-    gradient comes from `vidar_colsum_f32` (one HBM-rate pass) -- torch's generic reduction made ~250 calls / 6 ms of
-    a training step out of these column sums.  (The column-sum kernel combines its workgroups' partial sums with fp32
-    atomics: the bias gradient can differ in the last bits from run to run, unlike torch's `sum(0)`.)"""
+    gradient rides along with the weight gradient (`a_rowsum` of vidar_gemm_f32: no second pass over grad_out, summed in
+    a fixed order); only when the weight gradient takes the library product does it come from `vidar_colsum_f32` (one
+    HBM-rate pass whose workgroups combine with fp32 atomics: last-bit run-to-run differences)."""
 
     def forward(self, x, relu=False):
         """relu=True: ReLU(linear(x)) -- in the epilogue of the MFMA GEMM when that path is on"""
