@@ -650,12 +650,18 @@ __global__ __launch_bounds__(WS_THREADS, 2) void gemm_mfma_ws_kernel(GemmArgs g)
 // z-group order -- the order of the additions is fixed, the result is deterministic.
 __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* __restrict__ ws, int Z, GemmArgs g) {
   __shared__ f32x4 part[4][64];
-  if (g.a_rowsum != nullptr && blockIdx.x == gridDim.x - 1)      // the bias-gradient rows: z order, one thread per row
-    for (int m = threadIdx.x; m < g.M; m += 256) {
+  if (g.a_rowsum != nullptr) {
+    // the bias-gradient rows: a wave per row, rows dealt over the whole grid; lane l adds the partial rows z = l, l + 64,
+    // ... in order and the 64 lane sums are combined by a fixed butterfly -- the order of the additions never changes
+    const int lane = threadIdx.x & 63;
+    for (int m = (int)blockIdx.x * 4 + (threadIdx.x >> 6); m < g.M; m += (int)gridDim.x * 4) {
       float a = 0.f;
-      for (int z = 0; z < Z; ++z) a += g.rowsum_ws[(int64_t)z * g.M + m];
-      g.a_rowsum[m] = a;
+      for (int z = lane; z < Z; z += 64) a += g.rowsum_ws[(int64_t)z * g.M + m];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+      if (lane == 0) g.a_rowsum[m] = a;
     }
+  }
   const int64_t total = (int64_t)g.M * g.N;                  // a multiple of 4 is NOT required: the tail is scalar
   const int64_t quads = total >> 2;
   const int col = threadIdx.x & 63, zg = threadIdx.x >> 6;
