@@ -1,3 +1,11 @@
+"""Per-phase cycle counts of the step-parallel dvr kernels (csrc/dvr_par_kernels.h), EXPERIMENT build only:
+
+    VIDAR_EXTRA_HIPCC_FLAGS="-DVIDAR_PAR_TIMING" VIDAR_EXTRA_HIPCC_ONLY=dvr_family.hip python vidar_amd/build.py
+    python tools/dvr_par_timing.py            # on the GPU box; rebuild without the flag afterwards
+
+The flag makes lane 0 of every workgroup add `s_memtime` deltas at its barriers into a device array that
+`vidar_dbg_par_cycles` (only exported by that build) reads back: setup | allocation + chain 1 | rank | chain 2 | consume,
+summed over workgroups.  Numbers of round 5: profiles/r05_kbench_dvr_traversal.log."""
 import ctypes, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from vidar_amd.synthetic import ray_set
@@ -12,8 +20,8 @@ N, M = tindex.shape
 pred = torch.empty((N, M), device="cuda"); gt = torch.empty((N, M), device="cuda")
 L.vidar_dvr_set_traversal(1)
 def fwd(flags):
-    L.vidar_dvr_render_forward_f32(ptr(sigma), ptr(origin), ptr(points), ptr(tindex), ptr(pred), ptr(gt), N, M, 1, 1, 16, 200, 200, 1 | flags, stream_of(sigma))
-for name, flags in (("full", 0), ("no sigma load", 0x100), ("no expf", 0x200), ("neither", 0x300)):
+    L.vidar_dvr_render_forward_f32(ptr(sigma), ptr(origin), ptr(points), ptr(tindex), ptr(pred), ptr(gt), N, M, 1, 1, 16, 200, 200, 1, stream_of(sigma))
+for name, flags in (("render_forward", 0),):
     fwd(flags); L.vidar_dbg_par_cycles(buf, 1)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
