@@ -461,6 +461,22 @@ def kernel_rooflines(dev):
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}       # MI355X_MICROARCH.md: dense fp32 / bf16 matrix-core peaks
 
 
+def library_switches():
+    """the A/B switches the measured build ran with (each setter returns the previous value: read = set + restore), so
+    that two bench lines stay comparable when a default changes"""
+    from vidar_amd._lib import lib
+    L = lib()
+
+    def peek(fn, probe):
+        prev = fn(probe)
+        fn(prev)
+        return prev
+    return {"dvr_traversal": peek(L.vidar_dvr_set_traversal, -1), "dvr_sort_min_waves": peek(L.vidar_dvr_set_sort_min_waves, 1024),
+            "dvxlr_pad_mode": peek(L.vidar_dvxlr_set_pad_mode, 1), "gemm_variant": peek(L.vidar_gemm_set_variant, 0),
+            "msda_item_order": peek(L.vidar_msda_set_item_order, 1),
+            "gradient_exchange": os.environ.get("VIDAR_DDP", "flat"), "fused_adamw": os.environ.get("VIDAR_FUSED_ADAMW", "1") != "0"}
+
+
 def gemm_rooflines(dev):
     """`roofline_gemm`: the hand-written MFMA GEMM (csrc/gemm_mfma.hip) at the two shapes that matter -- the attention
     value projection the north star assigns to MFMA ([6*30825, 256] x [256, 256], spatial_cross_attention.py:333-340)
@@ -758,6 +774,10 @@ def main():
                                        "launches_per_step": all_dom["calls"] / args.steps,
                                        "ms_per_step": all_dom["total_ms"] / args.steps},
         }
+        try:
+            out["switches"] = library_switches()
+        except Exception as e:                                              # noqa: BLE001  (reporting only)
+            out["switches"] = {"error": str(e)[:100]}
         if extras:
             out["configs"] = extras
         if main_run["ddp"]:
