@@ -208,3 +208,13 @@ def test_relaunched_ranks_reach_the_rank_environment():
                        capture_output=True, text=True, timeout=600)
     out = r.stderr + r.stdout
     assert r.returncode != 0 and "re-running as" in out and out.count("needs a GPU") >= 2
+
+
+def test_bench_line_records_the_ab_switches():
+    """two bench lines are only comparable when they ran with the same switch settings: the line carries them, and
+    reading them leaves them as they were"""
+    import bench
+    first = bench.library_switches()
+    assert first == bench.library_switches()
+    assert first["dvr_traversal"] == -1 and first["gemm_variant"] == 0 and first["msda_item_order"] == 1
+    assert first["gradient_exchange"] in ("flat", "torch")
