@@ -44,11 +44,41 @@ def flops(name, shapes):
     return 0
 
 
+EAGER = ("aten::add", "aten::add_", "aten::mul", "aten::mul_", "aten::sub", "aten::div", "aten::copy_", "aten::cat", "aten::sum",
+         "aten::clone", "aten::contiguous", "aten::index", "aten::index_select", "aten::gather", "aten::where", "aten::sigmoid",
+         "aten::softmax", "aten::_softmax", "aten::relu", "aten::fill_", "aten::zero_", "aten::stack", "aten::masked_fill",
+         "aten::masked_fill_", "aten::native_dropout", "aten::native_layer_norm", "aten::mean", "aten::sqrt", "aten::exp",
+         "aten::addcmul", "aten::addcmul_", "aten::lerp_", "aten::_foreach_add_", "aten::new_zeros", "aten::zeros", "aten::zeros_like",
+         "aten::index_put_", "aten::_index_put_impl_", "aten::scatter_add_", "aten::sigmoid_backward", "aten::_softmax_backward_data",
+         "aten::native_dropout_backward", "aten::threshold_backward", "aten::permute", "aten::transpose")
+
+
+def eager_table(prof, args):
+    rows = defaultdict(int)
+    for ev in prof.events():
+        if ev.name in EAGER and ev.name not in ("aten::permute", "aten::transpose"):
+            shapes = tuple(tuple(s) for s in (ev.input_shapes or []) if isinstance(s, (list, tuple)) and len(s))
+            rows[(ev.name, shapes)] += 1
+
+    def nbytes(shapes):
+        return 4 * sum(int(np.prod(s)) for s in shapes)
+    out = Path(args.out)
+    out.parent.mkdir(parents=True, exist_ok=True)
+    lines = [f"# {args.config}: elementwise / copy / reduce aten ops of ONE training step (CPU activity; nested ops appear under both names)",
+             f"{'calls':>6} {'MB/call':>9} {'MB total':>10}  op  input shapes"]
+    for (name, shapes), n in sorted(rows.items(), key=lambda kv: -nbytes(kv[0][1]) * kv[1]):
+        lines.append(f"{n:6d} {nbytes(shapes) / 1e6:9.2f} {n * nbytes(shapes) / 1e6:10.1f}  {name}  {[list(s) for s in shapes]}")
+    out.write_text("\n".join(lines) + "\n")
+    print("\n".join(lines[:90]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="vidar_1_8_nusc_1future")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--out", default="gpurun_out/op_shapes.txt")
+    ap.add_argument("--eager", action="store_true", help="list the elementwise / copy / cat / reduce aten ops instead (the step's "
+                    "eager tail), ranked by calls x operand bytes")
     args = ap.parse_args()
     import bench
     from vidar_amd import gemm_tuning
@@ -71,6 +101,8 @@ def main():
         T.train_step(model, opt, batch, cfg["grad_clip"])
         torch.cuda.synchronize()
     rows = defaultdict(int)
+    if args.eager:
+        return eager_table(prof, args)
     for ev in prof.events():
         if ev.name in WANTED:
             shapes = tuple(tuple(s) for s in (ev.input_shapes or []) if isinstance(s, (list, tuple)))

@@ -106,9 +106,14 @@ class Linear(nn.Linear):
             return _gemm.linear(x, self.weight, self.bias, relu=relu)
         if (f32 and self.bias is not None and self.bias.requires_grad
                 and torch.is_grad_enabled() and n % 4 == 0 and (n // 4) & (n // 4 - 1) == 0 and n <= 4096):
-            y = _LinearColsum.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias).view(*x.shape[:-1], n)
-        else:
-            y = F.linear(x, self.weight, self.bias)
+            y = _LinearColsum.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias)
+            if relu:
+                # in place on the Function's own output, BEFORE the reshaping view: an in-place op on a view of a custom
+                # Function's output makes autograd rebase the graph on CopySlices, whose backward clones and copies the
+                # [rows, out_features] gradient three times (12 x 0.5 GB per step on the FFN's hidden layer)
+                y = F.relu(y, inplace=True)
+            return y.view(*x.shape[:-1], n)
+        y = F.linear(x, self.weight, self.bias)
         return F.relu(y, inplace=True) if relu else y
 
 
