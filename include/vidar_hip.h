@@ -391,6 +391,18 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
                          int pad, int dil, void* workspace, size_t workspace_bytes, void* stream);
 size_t vidar_dcn_col2im_workspace_bytes(int N, int H, int W, int Ho, int Wo, int kh, int kw);
 
+/* 3x3 convolution (stride 1, pad 1, dilation 1, groups 1) with FEW output channels as an implicit GEMM on the fp32
+ * matrix cores:  out[N,Cout,H,W] = conv2d(x[N,C,H,W], weight[Cout,C,3,3]) + bias  (bias may be NULL).
+ * Replaces the library convolution behind `conv_offset` of mmcv's ModulatedDeformConv2dPack -- the 3x3 that predicts the
+ * 18 offsets + 9 masks of every DCNv2 bottleneck (vidar_1_8_nusc_1future.py:93-95: DCNv2 on ResNet101 stages 3 and 4 =
+ * 26 of the backbone's 37 3x3 convolutions); its backward stays the library's.  fp32 products are exact, the sum runs
+ * channel-major with the 9 taps inside (within 1e-5 of an fp64 convolution, tests/test_conv3x3_gpu.py).
+ * workspace: vidar_conv3x3_few_workspace_bytes(C) bytes (the packed weights; written by the call).
+ * Limits (VIDAR_ERR_BAD_ARG otherwise): Cout <= 32, C % 8 == 0, W <= 191, H*W < 2^30. */
+size_t vidar_conv3x3_few_workspace_bytes(int C);
+int vidar_conv3x3_few_f32(const float* x, const float* weight, const float* bias, float* out, int N, int C, int H, int W,
+                          int Cout, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fused frozen-BatchNorm epilogue of the backbone: y = act(x*scale[c] + shift[c] (+ residual)),
  * NCHW, scale = gamma/sqrt(var+eps), shift = beta - mean*scale (BN is frozen / eval in every ViDAR
  * config: vidar_1_8_nusc_1future.py:93-95).  relu: 0/1.  residual / grad_residual may be NULL.

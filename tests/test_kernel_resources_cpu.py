@@ -29,8 +29,10 @@ def test_every_kernel_is_wave64_without_scratch_or_vgpr_spills(rows):
         assert r["wave"] == 64, r
         assert r["scratch"] == 0 and r["vgpr_spill"] == 0 and not r["dyn_stack"], r
         assert r["agpr"] == 0, r                 # the unified file is all arch VGPRs (the MFMA GEMM keeps its accumulators there too)
-        # the MFMA GEMM holds 64 accumulators + two staged operands (+ hi/lo fragments): 3 waves per SIMD by design
-        assert r["waves_per_simd"] >= (3 if r["kernel"].startswith("gemm_mfma_kernel<") else 4), r
+        # the MFMA GEMM holds 64 accumulators + two staged operands (+ hi/lo fragments): 3 waves per SIMD by design; the
+        # few-output 3x3 convolution fits 3 workgroups of 4 waves per CU in LDS (its slab), so 3 waves per SIMD is all it can use
+        by_design_3 = r["kernel"].startswith(("gemm_mfma_kernel<", "conv3x3_few_kernel<"))
+        assert r["waves_per_simd"] >= (3 if by_design_3 else 4), r
 
 
 def test_hot_kernels_are_present_with_the_documented_footprints(rows):

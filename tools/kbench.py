@@ -366,6 +366,27 @@ def bench_gemm(which):
         line(f"conv dw  6x[{Co},{HW}]x[{HW},{Ci}] {tag}", fl6, nb / 4, **ms)
 
 
+def bench_conv_offset(which):
+    """the DCNv2 `conv_offset` (3x3, C -> 27) at the backbone's four cases: csrc/conv3x3_mfma.hip vs the library convolution"""
+    import torch.nn.functional as F
+    from vidar_amd.plugin.backbones import _Conv3x3Few
+    torch.manual_seed(0)
+    for (N, C, H, W) in [(24, 256, 58, 100), (6, 256, 58, 100), (24, 512, 29, 50), (6, 512, 29, 50)]:
+        x = torch.randn(N, C, H, W, device="cuda")
+        w = torch.randn(27, C, 3, 3, device="cuda") * 0.02
+        b = torch.randn(27, device="cuda")
+        flops = 2 * 27 * C * 9 * N * H * W
+        with torch.no_grad():
+            ref = F.conv2d(x, w, b, padding=1)
+            got = _Conv3x3Few.apply(x, w, b)
+            err = float((got - ref).abs().max() / ref.abs().max())
+            ms_lib = timeit(lambda: F.conv2d(x, w, b, padding=1))
+            ms_own = timeit(lambda: _Conv3x3Few.apply(x, w, b))
+        report(f"conv_offset[{N},{C},{H},{W}] own", ms_own, 4 * (x.numel() + got.numel()), TFLOPs=round(flops / ms_own / 1e9, 1),
+               frac_fp32_mfma=round(flops * 32 / 27 / ms_own / 1e9 / 157.3, 3), rel_err_vs_lib=err)
+        report(f"conv_offset[{N},{C},{H},{W}] library", ms_lib, 4 * (x.numel() + got.numel()), TFLOPs=round(flops / ms_lib / 1e9, 1))
+
+
 def bench_gemm_pmc(which):
     """a few launches of the representative GEMM shapes per mode, for the counter passes (tools/pmc_pass.sh)"""
     from vidar_amd import gemm as G

@@ -16,7 +16,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .registry import BACKBONES, NECKS
-from .._lib import lib, check, ptr, stream_of, TIMER
+from .._lib import lib, check, ptr, stream_of, workspace, TIMER
 from .. import gemm as G
 
 
@@ -107,6 +107,52 @@ def modulated_deform_conv2d(x, offset, mask, weight, bias=None, stride=1, paddin
                                       scale, shift, bool(relu))
 
 
+# A/B switch of the DCNv2 `conv_offset` convolution: "own" = csrc/conv3x3_mfma.hip, "lib" (default) = the library
+# convolution.  Measured on MI355X (profiles/r05_kbench_conv_offset.log): 0.260 vs 0.246 ms on [24, 256, 58, 100], 0.105 vs
+# 0.094 ms on [6, 256, 58, 100], 0.193 vs 0.168 on [24, 512, 29, 50]; the step 344.6 vs 345.8 ms (inside the box-to-box
+# spread) -- parity at best, not a win, so the library keeps the default (why: profiles/r05_conv3x3_ablation.log).
+_CONV_OFFSET_OWN = os.environ.get("VIDAR_CONV_OFFSET", "lib") == "own"
+
+
+class _Conv3x3Few(Function):
+    """3x3 / stride 1 / pad 1 convolution with <= 32 output channels through csrc/conv3x3_mfma.hip (an implicit GEMM on the
+    fp32 matrix cores: the library's Winograd kernel cannot fill its tiles with 27 outputs); the backward is the very
+    `convolution_backward` autograd would issue for F.conv2d."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        w = weight.contiguous()
+        N, C, H, W = x.shape
+        Cout = w.shape[0]
+        out = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32)
+        ws, ws_ptr, ws_bytes = workspace(lib().vidar_conv3x3_few_workspace_bytes, C, like=x)
+        with TIMER.span("conv3x3_few", 4 * (x.numel() + out.numel())):
+            check(lib().vidar_conv3x3_few_f32(ptr(x), ptr(w), ptr(bias), ptr(out), N, C, H, W, Cout, ws_ptr, ws_bytes,
+                                              stream_of(x)), "conv3x3_few")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]]
+        gx, gw, gb = torch.ops.aten.convolution_backward(g.contiguous(), x, w, [w.shape[0]] if ctx.has_bias else None,
+                                                         [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
+        return gx, gw, gb
+
+
+def conv3x3_few_ok(conv, x):
+    """can `conv` (an nn.Conv2d) on `x` take the few-output implicit-GEMM kernel?  (include/vidar_hip.h lists the limits)"""
+    return (_CONV_OFFSET_OWN and x.is_cuda and x.dtype == torch.float32 and conv.weight.dtype == torch.float32
+            and not torch.is_autocast_enabled() and x.dim() == 4
+            and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.padding_mode == "zeros" and conv.out_channels <= 32 and conv.in_channels % 8 == 0
+            and x.shape[3] <= 191 and x.shape[2] * x.shape[3] < (1 << 30) and x.numel() > 0)
+
+
 class ModulatedDeformConv2dPack(nn.Module):
     """mmcv.ops.ModulatedDeformConv2dPack: `conv_offset` (zero-init conv -> 3*K channels), offsets =
     first 2K channels, mask = sigmoid(last K); parameters `weight`, (`bias`), `conv_offset.*`."""
@@ -127,7 +173,10 @@ class ModulatedDeformConv2dPack(nn.Module):
         nn.init.zeros_(self.conv_offset.bias)
 
     def forward(self, x, bn=None, relu=False):
-        out = self.conv_offset(x)
+        if conv3x3_few_ok(self.conv_offset, x):
+            out = _Conv3x3Few.apply(x, self.conv_offset.weight, self.conv_offset.bias)
+        else:
+            out = self.conv_offset(x)
         o1, o2, mask = torch.chunk(out, 3, dim=1)
         offset = torch.cat((o1, o2), dim=1)
         return modulated_deform_conv2d(x, offset, torch.sigmoid(mask), self.weight, self.bias,
