@@ -277,11 +277,19 @@ class Conv1x1(nn.Conv2d):
     torch GEMMs they go through the tuned library solutions of vidar_amd/gemm_tuning.py instead of MIOpen's default
     rocBLAS pick.  A stride > 1 subsamples the input first (what a strided 1x1 convolution computes)."""
     as_gemm = os.environ.get("VIDAR_CONV1X1_GEMM", "1") != "0"
+    any_device = False          # tests: take the GEMM form on the CPU too
 
-    def forward(self, x):
-        if not (self.as_gemm and x.is_cuda and self.kernel_size == (1, 1) and self.padding == (0, 0) and self.groups == 1):
+    def gemm_form(self, x):
+        return (self.as_gemm and (x.is_cuda or self.any_device) and self.kernel_size == (1, 1) and self.padding == (0, 0)
+                and self.groups == 1)
+
+    def forward(self, x, presampled=False):
+        """presampled: `x` already is the strided subsample `x[:, :, ::sh, ::sw]` (Bottleneck shares one copy between conv1
+        and the downsample convolution)"""
+        if not self.gemm_form(x):
+            assert not presampled
             return super().forward(x)
-        if self.stride != (1, 1):
+        if self.stride != (1, 1) and not presampled:
             x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous()
         N, C, H, W = x.shape
         out = torch.bmm(self.weight.view(1, self.out_channels, C).expand(N, -1, -1), x.reshape(N, C, H * W))
@@ -323,8 +331,11 @@ class _Conv1x1BNAct(Function):
         return gx, gw, None, None, (gres.view(N, Cout, H, W) if has_res else None), None, None
 
 
-def conv1x1_bn_act(conv, bn, x, residual=None, relu=False):
-    """`bn(conv(x), residual, relu)` of a bias-free 1x1 convolution and a frozen BN; fused when the MFMA GEMM path is on"""
+def conv1x1_bn_act(conv, bn, x, residual=None, relu=False, presampled=False):
+    """`bn(conv(x), residual, relu)` of a bias-free 1x1 convolution and a frozen BN; fused when the MFMA GEMM path is on.
+    presampled: `x` already is the convolution's strided subsample (see Conv1x1.forward)"""
+    if presampled:
+        return _conv1x1_bn_act_presampled(conv, bn, x, residual, relu)
     m = G.mode()
     # "auto": only the block's closing convolution (the one with a residual) takes the fused MFMA kernel -- there the
     # epilogue saves a 3-tensor affine_act pass; the other 1x1 convolutions are faster as library GEMM + affine_act
@@ -340,6 +351,21 @@ def conv1x1_bn_act(conv, bn, x, residual=None, relu=False):
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
     scale, shift = bn._scale_shift()
     return _Conv1x1BNAct.apply(x, conv.weight, scale, shift, residual, bool(relu), G.precision_of(m))
+
+
+def _conv1x1_bn_act_presampled(conv, bn, xs, residual, relu):
+    m = G.mode()
+    fuse = G.own_kernels(m) or (m == "auto" and residual is not None and _AUTO_FUSE_RES)
+    hw = xs.shape[2] * xs.shape[3]
+    in_range = 0 < hw < (1 << 22) and max(conv.in_channels, conv.out_channels) * hw < (1 << 29)
+    if (not fuse or not xs.is_cuda or bn.weight.requires_grad or conv.bias is not None or conv.kernel_size != (1, 1)
+            or conv.padding != (0, 0) or conv.groups != 1 or not in_range):
+        return bn(conv(xs, presampled=True), residual=residual, relu=relu)
+    scale, shift = bn._scale_shift()
+    return _Conv1x1BNAct.apply(xs, conv.weight, scale, shift, residual, bool(relu), G.precision_of(m))
+
+
+_SHARE_SUBSAMPLE = os.environ.get("VIDAR_SHARE_SUBSAMPLE", "1") != "0"
 
 
 class Bottleneck(nn.Module):
@@ -360,7 +386,22 @@ class Bottleneck(nn.Module):
         self.bn3 = FrozenBN(planes * 4, bn_grad)
         self.downsample = downsample
 
+    def _shares_subsample(self, x):
+        """caffe style puts the block's stride on conv1, and the downsample convolution has the same one: both 1x1
+        convolutions read the same strided subsample of x -- gather it once (one strided pass over x and, in the backward,
+        one scatter into zeros and a sum on the small tensor, instead of two of each)"""
+        d = self.downsample
+        return (_SHARE_SUBSAMPLE and d is not None and len(d) == 2 and isinstance(d[0], Conv1x1) and isinstance(d[1], FrozenBN)
+                and self.conv1.stride != (1, 1) and d[0].stride == self.conv1.stride
+                and self.conv1.gemm_form(x) and d[0].gemm_form(x))
+
     def forward(self, x):
+        if self._shares_subsample(x):
+            sh, sw = self.conv1.stride
+            xs = x[:, :, ::sh, ::sw].contiguous()
+            identity = conv1x1_bn_act(self.downsample[0], self.downsample[1], xs, presampled=True)
+            out = conv1x1_bn_act(self.conv1, self.bn1, xs, relu=True, presampled=True)
+            return self._tail(out, identity)
         if self.downsample is None:
             identity = x
         elif len(self.downsample) == 2 and isinstance(self.downsample[1], FrozenBN):
@@ -368,6 +409,9 @@ class Bottleneck(nn.Module):
         else:
             identity = self.downsample(x)
         out = conv1x1_bn_act(self.conv1, self.bn1, x, relu=True)
+        return self._tail(out, identity)
+
+    def _tail(self, out, identity):
         if (isinstance(self.conv2, ModulatedDeformConv2dPack) and G.own_kernels() and out.is_cuda
                 and not self.bn2.weight.requires_grad):
             out = self.conv2(out, bn=self.bn2, relu=True)
