@@ -63,12 +63,19 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-step", action="store_true",
                     help="also time the oracle port of the WHOLE step on a bounded sample (BEV 50x50; round-2 leg)")
+    ap.add_argument("--weights", default="trained_like",
+                    help="weight state of the timed model: `trained_like` (default: DCNv2 offsets ~N(0,(1.5 px)^2) with "
+                         "non-uniform masks, per-query deformable-attention offsets / logits -- the access pattern of a "
+                         "model that starts from the pretrained backbone the reference always loads, config :400; "
+                         "vidar_amd/weights.py), `init` (what init_weights leaves: zero DCNv2 offsets, one sampling ring "
+                         "per head -- the gather / scatter kernels' best case, rounds 1-5), or a `.pth` path (mmcv layout)")
     ap.add_argument("--extra-configs",
-                    default="vidar_1_8_nusc_3future!,vidar_1_8_nusc_1future@1:bf16x3!,"
+                    default="vidar_1_8_nusc_1future+init!,vidar_1_8_nusc_3future!,vidar_1_8_nusc_1future@1:bf16x3!,"
+                            "vidar_1_8_nusc_3future+init,"
                             "mem_efficient_vidar_1_8_nusc_3future,vidar_OpenScene_mini_full_3future,"
                             "vidar_1_8_nusc_3future@1:bf16x3,"
                             "vidar_full_nusc_1future@2,vidar_full_nusc_1future@4,vidar_full_nusc_1future@8",
-                    help="comma-separated `config[@samples_per_gpu][:gemm][!]` entries timed after the main one in the same "
+                    help="comma-separated `config[@samples_per_gpu][:gemm][+weights][!]` entries timed after the main one in the same "
                          "run (short records under `configs`, each with its peak device memory): BASELINE.json's other "
                          "named configs -- the north star's target sentence names vidar_1_8_nusc_3future (and the "
                          "reference's memory-efficient variant of it, README.md:143-148); OpenScene = 8 cameras; "
@@ -580,16 +587,18 @@ def make_batch(cfg, args, rank, dev, spg=None):
     return batch
 
 
-def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, gemm_mode=None, tune=True):
+def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, gemm_mode=None, tune=True,
+               weights=None):
     """build the model of one named config, time `steps` training steps -> dict(elapsed, ops, ddp, cfg, peak_mem_gb)"""
     from vidar_amd import gemm as G
     prev = G.set_mode(gemm_mode or G.mode())
     try:
         torch.cuda.reset_peak_memory_stats(dev)
         t0 = time.perf_counter()
-        r = _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg, tune)
+        r = _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg, tune, weights or args.weights)
         if rank == 0:
-            print(f"[bench] {name} spg={spg or args.samples_per_gpu} gemm={G.mode()}: {r['elapsed'] / steps * 1e3:.1f} ms/step "
+            print(f"[bench] {name} spg={spg or args.samples_per_gpu} gemm={G.mode()} weights={r['weights']['mode']}: "
+                  f"{r['elapsed'] / steps * 1e3:.1f} ms/step "
                   f"({time.perf_counter() - t0:.0f} s wall incl. build + warm-up)", file=sys.stderr, flush=True)
         r["gemm"] = G.mode()
         # the number next to the reference's only published figure for this path (README.md:143-148: ~63 GB for
@@ -605,9 +614,10 @@ GEMM_DTYPE = {"lib": "f32", "auto": "f32", "f32": "f32",
               "bf16x3": "f32 storage, bf16x3 MFMA products (16-bit significand >= TF32), f32 accumulate"}
 
 
-def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, tune=True):
+def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, tune=True, weights="init"):
     from vidar_amd import gemm_tuning
     from vidar_amd import train as T
+    from vidar_amd import weights as W
     from vidar_amd._lib import TIMER
     from vidar_amd._lib import lib as _hip
     from vidar_amd.configs import get_config
@@ -615,9 +625,12 @@ def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers
     torch.manual_seed(1234)                      # identical initial weights on every rank
     np.random.seed(1000 + rank)
     model = T.build_model(cfg).to(dev).train()
+    batch = make_batch(cfg, args, rank, dev, spg)
+    # the weight state is set BEFORE the data-parallel wrapper broadcasts rank 0's parameters: every rank then times the
+    # same model (the calibration pass of `trained_like` sees each rank's own batch)
+    wrep = W.prepare(model, batch, weights) if weights in W.MODES else W.prepare(model, batch, checkpoint=weights)
     ddp = T.wrap_ddp(model, local)
     opt = T.build_optimizer(model)
-    batch = make_batch(cfg, args, rank, dev, spg)
     grouped = dist.is_available() and dist.is_initialized()
 
     def after_warmup():
@@ -641,7 +654,7 @@ def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers
     info = ddp_info(ddp, world) if grouped else None
     del batch, ddp, opt, model
     torch.cuda.empty_cache()
-    return dict(elapsed=elapsed, ops=ops, ddp=info, cfg=cfg)
+    return dict(elapsed=elapsed, ops=ops, ddp=info, cfg=cfg, weights=wrep)
 
 
 def main():
@@ -687,11 +700,14 @@ def main():
         rigor = entry.endswith("!")
         entry = entry.rstrip("!")
         xsteps, xwarm = (args.steps, args.warmup) if rigor else (args.extra_steps, args.extra_warmup)
+        entry, _, xweights = entry.partition("+")
+        xweights = xweights or args.weights
         head, _, xgemm = entry.partition(":")
         name, _, xs = head.partition("@")
         xspg = int(xs) if xs else spg
         xgemm = xgemm or None
-        if name == args.config and xspg == spg and (xgemm or main_run["gemm"]) == main_run["gemm"]:
+        if (name == args.config and xspg == spg and (xgemm or main_run["gemm"]) == main_run["gemm"]
+                and xweights == args.weights):
             continue
         # an extra config must never cost the main measurement its record: a failure (e.g. out of memory at a large
         # per-GPU batch) is agreed on across ranks and written into the entry; so is running out of the time budget
@@ -700,12 +716,12 @@ def main():
         if grouped:
             dist.all_reduce(over, op=dist.ReduceOp.MAX)
         if float(over) > 0:
-            extras.append({"config": name, "samples_per_gpu": xspg, "gemm": xgemm or main_run["gemm"],
+            extras.append({"config": name, "samples_per_gpu": xspg, "gemm": xgemm or main_run["gemm"], "weights": xweights,
                            "skipped": f"extra-config time budget ({args.extra_budget_s:.0f} s) spent"})
             continue
         try:
             r = run_config(name, args, rank, local, world, dev, xsteps, xwarm, with_markers=False,
-                           spg=xspg, gemm_mode=xgemm, tune=False)
+                           spg=xspg, gemm_mode=xgemm, tune=False, weights=xweights)
         except Exception as e:                                              # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
             r = None
@@ -716,13 +732,14 @@ def main():
             if float(flag) > 0 and err is None:
                 err = "failed on another rank"
         if err:
-            extras.append({"config": name, "samples_per_gpu": xspg, "gemm": xgemm or main_run["gemm"], "error": err})
+            extras.append({"config": name, "samples_per_gpu": xspg, "gemm": xgemm or main_run["gemm"], "weights": xweights,
+                           "error": err})
             continue
         rec = {"config": name, "samples_per_gpu": xspg, "value": world * xspg * xsteps / r["elapsed"],
                "unit": "samples/s", "ms_per_step": r["elapsed"] / xsteps * 1e3, "steps": xsteps,
                "warmup": xwarm, "n_gpus": world, "global_batch": world * xspg,
                "cameras": r["cfg"]["num_cams"], "img_hw": list(r["cfg"]["img_hw"]), "gemm": r["gemm"],
-               "dtype": GEMM_DTYPE[r["gemm"]], "peak_mem_gb": round(r["peak_mem_gb"], 2),
+               "dtype": GEMM_DTYPE[r["gemm"]], "weights": r["weights"]["mode"], "peak_mem_gb": round(r["peak_mem_gb"], 2),
                "peak_reserved_gb": round(r["peak_reserved_gb"], 2)}
         if r["ops"]:
             dn, dv = max(((k, v) for k, v in r["ops"].items() if not k.startswith(("dcn_", "affine_act", "stem_", "gemm_"))),
@@ -755,6 +772,7 @@ def main():
             "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": GEMM_DTYPE[main_run["gemm"]], "data": "synthetic", "gemm": main_run["gemm"],
+            "weights": main_run["weights"],
             "peak_mem_gb": round(main_run["peak_mem_gb"], 2), "peak_reserved_gb": round(main_run["peak_reserved_gb"], 2),
             "config": {"workload": (f"{args.config}: images [1,5,{cfg['num_cams']},3,{cfg['img_hw'][0]}x"
                                     f"{cfg['img_hw'][1]}] -> ResNet101-DCNv2 + FPN -> " if not args.no_backbone

@@ -179,8 +179,9 @@ class ModulatedDeformConv2dPack(nn.Module):
             out = self.conv_offset(x)
         o1, o2, mask = torch.chunk(out, 3, dim=1)
         offset = torch.cat((o1, o2), dim=1)
+        fuse = dict(bn=bn, relu=relu) if bn is not None else {}     # (the epilogue-fused form exists on the MFMA GEMM path only)
         return modulated_deform_conv2d(x, offset, torch.sigmoid(mask), self.weight, self.bias,
-                                       self.stride, self.padding, self.dilation, bn=bn, relu=relu)
+                                       self.stride, self.padding, self.dilation, **fuse)
 
 
 class _AffineAct(Function):
