@@ -73,3 +73,23 @@ def test_full_size_properties():
     same = knn_points(ta, ta)
     assert float(same.dists.sum()) == 0.0
     assert bool((same.idx[0, :, 0] == torch.arange(30000, device="cuda")).all())
+
+
+@pytest.mark.parametrize("D,K", [(3, 3), (2, 1), (5, 4), (3, 9)])
+def test_generic_knn_on_the_device_matches_the_reference_build(D, K, ref_modules):
+    """K != 1 or D != 3 (not on ViDAR's path; the reference dispatches them, knn.cu:266-295): the public entry points
+    run them as a device program -- same indices / distances / gradients as the reference's knn_cpu.cpp build, through
+    `knn_points` with autograd like a drop-in user would call it."""
+    from test_knn_generic_cpu import _clouds
+    from vidar_amd.third_lib.chamferdist import knn_points
+    ref = ref_modules("ref_chamferdist_C")
+    a, b, l1, l2 = _clouds(7 * D + K, 2, 301, 157, D, ties=True)
+    ri, rd = ref.knn_points_idx(a, b, l1, l2, K, -1)
+    ga, gb = a.cuda().requires_grad_(), b.cuda().requires_grad_()
+    out = knn_points(ga, gb, l1.cuda(), l2.cuda(), K=K)
+    assert out.idx.is_cuda and torch.equal(out.idx.cpu(), ri) and torch.equal(out.dists.detach().cpu(), rd)
+    g = torch.from_numpy(np.random.default_rng(1).standard_normal(tuple(rd.shape)).astype(np.float32))
+    out.dists.backward(g.cuda())
+    r1, r2 = ref.knn_points_backward(a, b, l1, l2, ri, g)
+    torch.testing.assert_close(ga.grad.cpu(), r1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gb.grad.cpu(), r2, rtol=1e-5, atol=1e-4)

@@ -1,7 +1,10 @@
 """`chamferdist._C` -- same callables as the reference's pybind module
 (third_lib/chamfer_dist/chamferdist/chamferdist/ext.cpp:5-11).  The hot case K=1, D=3 runs the
 gfx950 HIP kernel behind vidar_knn1_d3_{fwd,bwd}; other (D, K) are not on ViDAR's path
-(every call site uses K=1 on xyz clouds: chamfer.py:77-93) and raise NotImplementedError."""
+(every call site uses K=1 on xyz clouds: chamfer.py:77-93): the reference dispatches them to templated kernels
+(knn.cu:266-295), here they run as a chunked torch program ON THE DEVICE of the inputs (`_generic_*` below: same
+results as knn_cpu.cpp:7-58 / :64-106 -- ascending distances, ties to the lower index, zero rows past `lengths1`,
+zero slots past `lengths2`), not a host fallback: CPU tensors are refused exactly like in the hot case."""
 from __future__ import annotations
 
 import torch
@@ -10,8 +13,17 @@ from ..._lib import lib, check, ptr, stream_of, TIMER
 
 
 def knn_check_version(version: int, D: int, K: int) -> bool:
-    """knn.cu:237-253 semantics restricted to the one implementation we ship."""
-    return version in (-1, 3) and D == 3 and K == 1
+    """KnnCheckVersion (knn.cu:269-280): which of the reference's four kernels accepts (D, K).  Every accepted
+    combination computes the same result here (one HIP kernel for D = 3, K = 1; the device program below otherwise)."""
+    if version == 0:
+        return True
+    if version == 1:
+        return 1 <= D <= 32
+    if version == 2:
+        return 1 <= D <= 8 and 1 <= K <= 32
+    if version == 3:
+        return 1 <= D <= 8 and 1 <= K <= 4
+    return False
 
 
 def _prep(p1, p2, lengths1, lengths2):
@@ -19,19 +31,78 @@ def _prep(p1, p2, lengths1, lengths2):
         raise RuntimeError("p1/p2 must be CUDA tensors (vidar_amd has no CPU path)")
     if p1.dtype != torch.float32 or p2.dtype != torch.float32:
         raise RuntimeError("p1/p2 must be float32")
-    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != 3 or p2.shape[2] != 3:
-        raise NotImplementedError("only D == 3 point clouds are supported")
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[2] != p2.shape[2]:
+        raise RuntimeError("p1/p2 must be [N, P, D] with the same D")
     if p1.shape[0] != p2.shape[0]:
         raise RuntimeError("batch sizes differ")
     return (p1.contiguous(), p2.contiguous(), lengths1.to(torch.int64).contiguous(),
             lengths2.to(torch.int64).contiguous())
 
 
+_GENERIC_CHUNK_ELEMS = 1 << 25          # distance-matrix elements per chunk of p1 rows (128 MiB of fp32 + the sort's indices)
+
+
+def _generic_knn_idx(p1, p2, l1, l2, K):
+    """knn_cpu.cpp:7-58 as a tensor program on p1's device: for every valid row of p1 the K nearest valid points of p2,
+    squared L2 accumulated over d = 0..D-1 in fp32 with separately rounded products (the CPU build's arithmetic),
+    ascending, ties to the lower index (a STABLE sort: the priority queue keeps the first-seen of equal distances and
+    pops them in (distance, index) order); rows >= lengths1 and slots >= lengths2 stay zero like `torch::full(.., 0)`."""
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    idx = torch.zeros((N, P1, K), dtype=torch.int64, device=p1.device)
+    dist = torch.zeros((N, P1, K), dtype=torch.float32, device=p1.device)
+    if N == 0 or P1 == 0 or P2 == 0 or K == 0:
+        return idx, dist
+    kk = min(K, P2)
+    rows = max(1, _GENERIC_CHUNK_ELEMS // P2)
+    col = torch.arange(P2, device=p1.device)
+    slot = torch.arange(kk, device=p1.device)
+    row = torch.arange(P1, device=p1.device)
+    for n in range(N):
+        col_ok = col < l2[n]                                             # [P2]
+        slot_ok = slot < l2[n]                                           # [kk]
+        for r0 in range(0, P1, rows):
+            a = p1[n, r0:r0 + rows]                                      # [R, D]
+            d = None
+            for k in range(D):
+                diff = a[:, k, None] - p2[n, None, :, k]
+                sq = diff * diff
+                d = sq if d is None else d + sq
+            d = torch.where(col_ok[None], d, torch.full_like(d, float("inf")))
+            dv, di = torch.sort(d, dim=1, stable=True)
+            keep = slot_ok[None] & (row[r0:r0 + rows, None] < l1[n])     # [R, kk]
+            dist[n, r0:r0 + rows, :kk] = torch.where(keep, dv[:, :kk], torch.zeros_like(dv[:, :kk]))
+            idx[n, r0:r0 + rows, :kk] = torch.where(keep, di[:, :kk], torch.zeros_like(di[:, :kk]))
+    return idx, dist
+
+
+def _generic_knn_backward(p1, p2, l1, l2, idxs, grad_dists):
+    """knn_cpu.cpp:64-106 (== knn.cu:443-544): d dist / d p1 = 2 g (p1 - p2[idx]), scattered with the opposite sign to
+    p2[idx]; only rows < lengths1 and slots < min(lengths2, K) contribute."""
+    N, P1, D = p1.shape
+    K = idxs.shape[2]
+    g1 = torch.zeros_like(p1)
+    g2 = torch.zeros_like(p2)
+    if N == 0 or P1 == 0 or K == 0 or p2.shape[1] == 0:
+        return g1, g2
+    row_ok = torch.arange(P1, device=p1.device)[None, :, None] < l1[:, None, None]
+    slot_ok = torch.arange(K, device=p1.device)[None, None, :] < l2[:, None, None]
+    w = torch.where(row_ok & slot_ok, grad_dists, torch.zeros_like(grad_dists))          # [N, P1, K]
+    ii = torch.where(row_ok & slot_ok, idxs, torch.zeros_like(idxs))
+    nb = p2.gather(1, ii.reshape(N, P1 * K, 1).expand(-1, -1, D)).view(N, P1, K, D)
+    diff = 2.0 * w[..., None] * (p1[:, :, None, :] - nb)                                  # [N, P1, K, D]
+    g1 = diff.sum(2)
+    g2.scatter_add_(1, ii.reshape(N, P1 * K, 1).expand(-1, -1, D), -diff.reshape(N, P1 * K, D))
+    return g1, g2
+
+
 def knn_points_idx(p1, p2, lengths1, lengths2, K: int = 1, version: int = -1):
     """-> (idx int64 [N,P1,K], dists f32 [N,P1,K]) ; squared L2, ties -> lowest index."""
-    if K != 1:
-        raise NotImplementedError("only K == 1 is supported")
     p1, p2, l1, l2 = _prep(p1, p2, lengths1, lengths2)
+    if version >= 0 and not knn_check_version(version, p1.shape[2], K):
+        raise RuntimeError("Invalid version")                   # AT_ASSERTM(KnnCheckVersion(version, D, K), ...) knn.cu:318
+    if K != 1 or p1.shape[2] != 3:
+        return _generic_knn_idx(p1, p2, l1.to(p1.device), l2.to(p1.device), int(K))
     N, P1, _ = p1.shape
     P2 = p2.shape[1]
     idx = torch.empty((N, P1, 1), dtype=torch.int64, device=p1.device)
@@ -45,9 +116,10 @@ def knn_points_idx(p1, p2, lengths1, lengths2, K: int = 1, version: int = -1):
 
 def knn_points_backward(p1, p2, lengths1, lengths2, idxs, grad_dists):
     """-> (grad_p1 [N,P1,3], grad_p2 [N,P2,3])   (knn_cpu.cpp:64-106)"""
-    if idxs.shape[-1] != 1:
-        raise NotImplementedError("only K == 1 is supported")
     p1, p2, l1, l2 = _prep(p1, p2, lengths1, lengths2)
+    if idxs.shape[-1] != 1 or p1.shape[2] != 3:
+        return _generic_knn_backward(p1, p2, l1.to(p1.device), l2.to(p1.device), idxs.contiguous(),
+                                     grad_dists.contiguous().float())
     N, P1, _ = p1.shape
     P2 = p2.shape[1]
     g1 = torch.empty_like(p1)
