@@ -61,3 +61,46 @@ def test_ddp_two_ranks_gloo():
     a = _run("flat")
     b = _run("torch")
     assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (a, b)
+
+
+def _unused_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vidar_amd import train as T
+    T.init_distributed()
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(3, 1)
+            self.only_rank0 = torch.nn.Parameter(torch.ones(3))
+            self.never = torch.nn.Parameter(torch.ones(2))
+
+        def forward(self, x, use):
+            y = self.a(x).sum()
+            return y + (self.only_rank0 * x[0]).sum() if use else y
+    torch.manual_seed(0)
+    m = T.FlatAllReduce(Toy())
+    x = torch.full((2, 3), float(rank + 1))
+    m(x, use=rank == 0).backward()
+    m.reduce_gradients()
+    t = m.module
+    out[rank] = (t.never.grad is None, t.only_rank0.grad.tolist(), t.a.weight.grad.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_all_reduce_leaves_grad_none_where_no_rank_produced_one():
+    """the 1-GPU step skips a parameter without a gradient (train_step's `p.grad is not None` filter); the flat exchange
+    must not turn that into a zero gradient (AdamW would decay the weight), and a gradient only SOME ranks produced is
+    still averaged over all of them"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_unused_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        never_none, only0, aw = out[r]
+        assert never_none
+        assert only0 == [0.5, 0.5, 0.5]                    # rank 0: x[0] = 1 -> grad 1; rank 1: none -> 0; mean 0.5
+        assert aw == [[3.0, 3.0, 3.0]]                     # (2 * 1 + 2 * 2) / 2

@@ -332,21 +332,27 @@ class _Conv1x1BNAct(Function):
         return gx, gw, None, None, (gres.view(N, Cout, H, W) if has_res else None), None, None
 
 
+def _fuses_1x1(conv, bn, x, residual, hw, m):
+    """does `bn(conv(x))` (+ residual, ReLU) take the fused MFMA kernel?  hw = output pixels per image.
+    "auto": only the block's closing convolution (the one with a residual) does -- there the epilogue saves a 3-tensor
+    affine_act pass; the other 1x1 convolutions are faster as library GEMM + affine_act.  Beyond the kernel's
+    addressing range -- H*W >= 2^22 or channels x H*W >= 2^29, gemm.operand_ok -- the library convolution runs as in
+    every other mode."""
+    fuse = G.own_kernels(m) or (m == "auto" and residual is not None and _AUTO_FUSE_RES)
+    in_range = 0 < hw < (1 << 22) and max(conv.in_channels, conv.out_channels) * hw < (1 << 29)
+    return (fuse and x.is_cuda and not bn.weight.requires_grad and conv.bias is None and conv.kernel_size == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and in_range)
+
+
 def conv1x1_bn_act(conv, bn, x, residual=None, relu=False, presampled=False):
     """`bn(conv(x), residual, relu)` of a bias-free 1x1 convolution and a frozen BN; fused when the MFMA GEMM path is on.
     presampled: `x` already is the convolution's strided subsample (see Conv1x1.forward)"""
     if presampled:
         return _conv1x1_bn_act_presampled(conv, bn, x, residual, relu)
     m = G.mode()
-    # "auto": only the block's closing convolution (the one with a residual) takes the fused MFMA kernel -- there the
-    # epilogue saves a 3-tensor affine_act pass; the other 1x1 convolutions are faster as library GEMM + affine_act
-    fuse = G.own_kernels(m) or (m == "auto" and residual is not None and _AUTO_FUSE_RES)
-    hw = (x.shape[2] // conv.stride[0]) * (x.shape[3] // conv.stride[1]) if x.dim() == 4 else 0
-    # (beyond the kernel's addressing range -- H*W >= 2^22 or channels x H*W >= 2^29, gemm.operand_ok -- the library
-    #  convolution runs as in every other mode)
-    in_range = 0 < hw < (1 << 22) and max(conv.in_channels, conv.out_channels) * hw < (1 << 29)
-    if (not fuse or not x.is_cuda or bn.weight.requires_grad or conv.bias is not None or conv.kernel_size != (1, 1)
-            or conv.padding != (0, 0) or conv.groups != 1 or not in_range):
+    # a strided 1x1 convolution keeps ceil(H / s) x ceil(W / s) pixels
+    hw = ((x.shape[2] - 1) // conv.stride[0] + 1) * ((x.shape[3] - 1) // conv.stride[1] + 1) if x.dim() == 4 else 0
+    if not _fuses_1x1(conv, bn, x, residual, hw, m):
         return bn(conv(x), residual=residual, relu=relu)
     if conv.stride != (1, 1):
         x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
@@ -356,11 +362,7 @@ def conv1x1_bn_act(conv, bn, x, residual=None, relu=False, presampled=False):
 
 def _conv1x1_bn_act_presampled(conv, bn, xs, residual, relu):
     m = G.mode()
-    fuse = G.own_kernels(m) or (m == "auto" and residual is not None and _AUTO_FUSE_RES)
-    hw = xs.shape[2] * xs.shape[3]
-    in_range = 0 < hw < (1 << 22) and max(conv.in_channels, conv.out_channels) * hw < (1 << 29)
-    if (not fuse or not xs.is_cuda or bn.weight.requires_grad or conv.bias is not None or conv.kernel_size != (1, 1)
-            or conv.padding != (0, 0) or conv.groups != 1 or not in_range):
+    if not _fuses_1x1(conv, bn, xs, residual, xs.shape[2] * xs.shape[3] if xs.dim() == 4 else 0, m):
         return bn(conv(xs, presampled=True), residual=residual, relu=relu)
     scale, shift = bn._scale_shift()
     return _Conv1x1BNAct.apply(xs, conv.weight, scale, shift, residual, bool(relu), G.precision_of(m))

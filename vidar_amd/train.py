@@ -104,19 +104,31 @@ class FlatAllReduce(torch.nn.Module):
 
     def reduce_gradients(self):
         # every rank must contribute the same layout: all trainable parameters in module order, a parameter that got
-        # no gradient on this rank contributes zeros (the hot path gives every trainable parameter a gradient every
-        # step, tests/test_ddp_cpu.py -- this only keeps an unusual batch from dead-locking the collective)
+        # no gradient on this rank contributes zeros.  One extra float per parameter rides along ("this rank produced a
+        # gradient"): a parameter NO rank produced a gradient for keeps grad None afterwards -- the optimizer then skips
+        # it exactly like the 1-GPU step does (AdamW would otherwise apply weight decay and decay its moments; the
+        # reference's DDP, find_unused_parameters=False (apis/mmdet_train.py:71-79), refuses such a step instead).
+        # The mask is only read back (one host sync) on a rank that itself missed a gradient -- never on the hot path,
+        # which gives every trainable parameter a gradient every step (tests/test_ddp_cpu.py).
         params = [p for p in self.module.parameters() if p.requires_grad]
         if not params:
             return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+        have = [p.grad is not None for p in params]
+        ref = next((p.grad for p in params if p.grad is not None), params[0])
+        mask = torch.tensor([1.0 if h else 0.0 for h in have], dtype=ref.dtype, device=ref.device)
+        flat = torch.cat([(p.grad if h else torch.zeros_like(p)).reshape(-1) for p, h in zip(params, have)] + [mask])
+        n_grad = flat.numel() - len(params)
         if self.world > 1:
-            flat.div_(self.world)
+            flat[:n_grad].div_(self.world)
         dist.all_reduce(flat)
+        nobody = set()
+        if not all(have):
+            total = flat[n_grad:].cpu()
+            nobody = {i for i, h in enumerate(have) if not h and float(total[i]) == 0.0}
         off = 0
-        for p in params:
+        for i, p in enumerate(params):
             n = p.numel()
-            p.grad = flat[off:off + n].view_as(p)
+            p.grad = None if i in nobody else flat[off:off + n].view_as(p)
             off += n
         self.last_bytes = flat.numel() * flat.element_size()
 
