@@ -181,11 +181,6 @@ size_t vidar_msda_bwd_workspace_bytes(int B, int Nv, int H, int Nq, int L, int P
  * each of the 8 XCDs only reads its own head's plane of `value` (it fits the XCD's 4 MiB L2); 0 = 4 queries x 8 heads in
  * contiguous query bands per XCD (rounds 1-3).  Results do not depend on it.  Returns the previous value. */
 int vidar_msda_set_item_order(int head_major);
-/* A/B switch of the accumulate kernel of the destination-binned backward (workspace != NULL): 1 (default) = the wave sorts
- * its chunk of a tile's samples by window line in LDS and accumulates each run of equal lines in registers (one LDS
- * read-modify-write per run); 0 = one LDS read-modify-write per sample (rounds 2-5).  Same result up to fp32 summation
- * order.  Other values are ignored.  Returns the previous value. */
-int vidar_msda_set_tile_variant(int variant);
 int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* sampling_loc,
                        const float* attn_weight, const float* grad_out, float* grad_value,

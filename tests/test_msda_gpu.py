@@ -32,18 +32,7 @@ CASES = [
     ("hot_tile", 1, [(3, 3)], 5000, 8),                # > 1024 samples per destination tile -> several chunks
     ("max_samples_per_item", 1, [(10, 12), (5, 6), (3, 3), (2, 2)], 70, 16),   # L*P = 64: 66.5 KB of record LDS (opt-in > 64 KiB)
 ]
-SCATTER = {"atomic": False, "binned": True, "binned_rmw": True}
-
-
-@pytest.fixture(autouse=True)
-def tile_variant(request):
-    """scatter = "binned": the default accumulate kernel of the destination-binned backward (line-sorted runs in
-    registers); "binned_rmw": the rounds 2-5 kernel (one LDS read-modify-write per sample), vidar_msda_set_tile_variant"""
-    from vidar_amd._lib import lib
-    params = getattr(getattr(request.node, "callspec", None), "params", {})
-    prev = lib().vidar_msda_set_tile_variant(0 if params.get("scatter") == "binned_rmw" else 1)
-    yield
-    lib().vidar_msda_set_tile_variant(prev)
+SCATTER = {"atomic": False, "binned": True}
 
 
 def run(B, shapes, Nq, P, H=8, seed=0, binned=None):

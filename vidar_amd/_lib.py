@@ -30,9 +30,6 @@ def lib() -> ctypes.CDLL:
         order = os.environ.get("VIDAR_MSDA_ITEM_ORDER")          # A/B of the MSDA gather kernels' item order (tools, bench)
         if order is not None:
             _lib.vidar_msda_set_item_order(int(order))
-        variant = os.environ.get("VIDAR_MSDA_TILE_VARIANT")      # A/B of the binned backward's accumulate kernel
-        if variant is not None:
-            _lib.vidar_msda_set_tile_variant(int(variant))
     return _lib
 
 

@@ -458,12 +458,7 @@ static_assert(kWinLines < 128, "the window line index shares a word with a 128-b
 #ifndef VIDAR_MSDA_CHUNK
 #define VIDAR_MSDA_CHUNK 1024
 #endif
-constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor of the read-modify-write accumulate kernel
-#ifndef VIDAR_MSDA_SEG_CHUNK
-#define VIDAR_MSDA_SEG_CHUNK 512
-#endif
-constexpr int kSegChunk = VIDAR_MSDA_SEG_CHUNK; // ... of the line-sorted accumulate kernel (its sorted records live in LDS)
-static_assert(kSegChunk % 64 == 0 && kSegChunk <= kChunk, "the workspace is sized for the smaller chunk");
+constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor (tuning sweep: tools/tune_msda_tile.sh)
 constexpr int kMaxL = 16;                      // levels supported by the binned path
 constexpr int kTWaves = 4;                     // waves (= chunks, private 10 KB windows) per workgroup of the accumulate kernel
 // (16-byte sort records {x, y, attention weight, sample} that the accumulate kernel would read coalesced instead of
@@ -576,7 +571,7 @@ constexpr int kScanPer = 8;                            // consecutive bins per t
 constexpr int kScanSlab = kScanThreads * kScanPer;
 __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
     const int64_t* __restrict__ shapes, const int* __restrict__ counts, int* __restrict__ cursor,
-    int4* __restrict__ desc, int* __restrict__ n_chunks, int B, int H, int L, int chunk) {
+    int4* __restrict__ desc, int* __restrict__ n_chunks, int B, int H, int L) {
   __shared__ LevelTab t;
   __shared__ int s_wsum[kScanThreads / 64], s_wchk[kScanThreads / 64];
   build_tab(t, shapes, L);
@@ -589,7 +584,7 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
   int ps = 0, pk = 0;
   for (int i = threadIdx.x; i < base; i += kScanThreads) {
     const int c0 = counts[i];
-    ps += c0; pk += (c0 + chunk - 1) / chunk;
+    ps += c0; pk += (c0 + kChunk - 1) / kChunk;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { ps += __shfl_xor(ps, d, 64); pk += __shfl_xor(pk, d, 64); }
@@ -604,7 +599,7 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
   for (int j = 0; j < kPer; ++j) { const int bin = base + threadIdx.x * kPer + j; c[j] = bin < nbins ? counts[bin] : 0; }
   int ts = 0, tk = 0;
 #pragma unroll
-  for (int j = 0; j < kPer; ++j) { ts += c[j]; tk += (c[j] + chunk - 1) / chunk; }
+  for (int j = 0; j < kPer; ++j) { ts += c[j]; tk += (c[j] + kChunk - 1) / kChunk; }
   int xs = ts, xk = tk;                                // inclusive wave scans of the per-thread totals
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -631,8 +626,8 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
   for (int j = 0; j < kPer; ++j, ++bin) {
     if (bin < nbins) {
       cursor[bin] = s;
-      for (int i = 0; i < c[j]; i += chunk) {
-        desc[2 * kk] = make_int4(s + i, min(chunk, c[j] - i), l, b);
+      for (int i = 0; i < c[j]; i += kChunk) {
+        desc[2 * kk] = make_int4(s + i, min(kChunk, c[j] - i), l, b);
         desc[2 * kk + 1] = make_int4(h, ty, tx, 0);
         ++kk;
       }
@@ -742,152 +737,6 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
       for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
     }
   }
-  // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
-  float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
-  for (int i = half; i < kWinLines; i += 2) {
-    const int r = i / kWin, c = i - r * kWin;
-    const int py = ty * kTile + r - 1, px = tx * kTile + c - 1;
-    if (py < 0 || py >= Hl || px < 0 || px >= Wl) continue;
-    const float v = win[i * kCh + ch];
-    if (v != 0.f) unsafeAtomicAdd(gv + ((int64_t)py * Wl + px) * H * kCh, v);
-  }
-}
-
-// Accumulate kernel, line-sorted form (round 6; the default).  The kernel above pays one LDS read -> fma -> write
-// round trip per sample and corner row: consecutive samples of a chunk may hit the same window line, so the compiler
-// (and the hardware, in order) must finish sample j's update before sample j+1 reads -- ~400 clocks per sample and
-// wave, hidden only by the 12-14 waves whose windows fit a CU.  Here the wave first SORTS its chunk by the window line
-// of the top-left corner (a counting sort over the 64 positions of the 8x8 tile, in LDS: one ds_add per sample for the
-// histogram, one returning ds_add for the slot), then walks the sorted records: all samples of a run update the same
-// four window cells per lane pair, so they accumulate in two REGISTERS (top row, bottom row of this lane's column) and
-// touch the LDS window once per run -- <= 64 read-modify-writes per chunk instead of one per sample -- while the
-// per-sample stream (weight pair from LDS, grad_out line through the buffer descriptor, two fmas) has no dependent
-// chain left.  Records are sorted in LDS as {lw, lh, attention weight, grad_out line offset | window line}: the chunk
-// size is kSegChunk (16 bytes x 512 = 8 KB per wave next to the 10 KB window).
-constexpr int kSegWaves = 4;
-constexpr int kSegBatches = kSegChunk / 64;
-
-__global__ __launch_bounds__(64 * kSegWaves) void msda_bwd_tile_seg_kernel(
-    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
-    const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
-    const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
-    int H, int L, int P, int go_bytes) {
-  __shared__ __attribute__((aligned(16))) float s_win[kSegWaves][kWinLines * kCh];
-  __shared__ float4 s_srt[kSegWaves][kSegChunk];       // the chunk's records, sorted by window line
-  __shared__ float4 s_par[kSegWaves][64];              // per wave and sample: {top-left, bottom-left, top-right, bottom-right}
-  __shared__ int s_hist[kSegWaves][kTile * kTile];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int chunk = blockIdx.x * kSegWaves + wave;
-  if (chunk >= *n_chunks) return;                      // wave-uniform
-  const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
-  const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
-  const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-  float* win = s_win[wave];
-  float4* srt = s_srt[wave];
-  int* hist = s_hist[wave];
-  const int half = lane >> 5, ch = lane & 31;
-  float* wq = win + half * kCh + ch;                   // + (window line of the top-left corner) * kCh
-  const float2* par = reinterpret_cast<const float2*>(&s_par[wave][0]) + half;
-  const int LP = L * P;
-  const __amdgpu_buffer_rsrc_t go_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
-  for (int i = lane; i < kWinLines * kCh / 4; i += 64) reinterpret_cast<float4*>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  static_assert(kTile * kTile == 64, "one histogram bin per lane");
-  hist[lane] = 0;
-  __builtin_amdgcn_wave_barrier();
-  // pass 1: every lane loads its samples of the chunk (kept in registers) and counts their keys
-  float4 mine[kSegBatches];                            // {lw, lh, attention weight, pack}
-  int key[kSegBatches];
-#pragma unroll
-  for (int i = 0; i < kSegBatches; ++i) {
-    key[i] = -1;
-    if (i * 64 < n) {                                  // wave-uniform
-      const bool valid = i * 64 + lane < n;
-      const int s = rec[s0 + (valid ? i * 64 + lane : 0)];
-      const float2 xy = reinterpret_cast<const float2*>(loc)[s];
-      const float aw = attw[s];
-      const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
-      const int h0 = (int)floorf(y), w0 = (int)floorf(x);
-      const int r = min(max(h0 + 1 - ty * kTile, 0), kTile - 1), c = min(max(w0 + 1 - tx * kTile, 0), kTile - 1);
-      // one word for the v_readlane hand-off: byte offset of the sample's grad_out line (a multiple of 128) | window line
-      mine[i] = make_float4(x - w0, y - h0, aw, __int_as_float(((s / LP) * (kCh * 4)) | (r * kWin + c)));
-      if (valid) { key[i] = r * kTile + c; atomicAdd(hist + key[i], 1); }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  // exclusive prefix of the 64 counts (lane = key)
-  {
-    const int c = hist[lane];
-    int x = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int u = __shfl_up(x, d, 64);
-      if (lane >= d) x += u;
-    }
-    __builtin_amdgcn_wave_barrier();
-    hist[lane] = x - c;
-  }
-  __builtin_amdgcn_wave_barrier();
-  // pass 2: scatter the records to their sorted slots
-#pragma unroll
-  for (int i = 0; i < kSegBatches; ++i)
-    if (i * 64 < n && key[i] >= 0) srt[atomicAdd(hist + key[i], 1)] = mine[i];
-  __builtin_amdgcn_wave_barrier();
-  int cur = -1;                                        // window line of the run being accumulated (wave-uniform)
-  float acc_t = 0.f, acc_b = 0.f;                      // this lane's column: top row / bottom row of the run's footprint
-  for (int base = 0; base < n; base += 64) {
-    // lane k prepares sorted sample base+k: the four corner weights (times the attention weight); lanes past the end of
-    // the chunk carry zero weights and the LAST valid sample's line, so they neither add nor end a run
-    const int last = min(63, n - 1 - base);
-    const float4 q = srt[base + min(lane, last)];
-    const bool valid = lane <= last;
-    const float lw = q.x, lh = q.y, aw = valid ? q.z : 0.f;
-    const float hh = (1.f - lh) * aw, lha = lh * aw;
-    __builtin_amdgcn_wave_barrier();                   // the previous batch's reads of s_par are done (in-order LDS)
-    s_par[wave][lane] = make_float4(hh * (1.f - lw), lha * (1.f - lw), hh * lw, lha * lw);
-    const int pack = __float_as_int(q.w);
-    __builtin_amdgcn_wave_barrier();
-    float g[8], gn[8];
-    float2 a[8], an[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      g[u] = go_one(go_rsrc, ch * 4, __builtin_amdgcn_readlane(pack, u) & ~127);
-      a[u] = par[2 * u];                               // (top, bottom) weight of this lane's column
-    }
-#pragma unroll
-    for (int j0 = 0; j0 < 64; j0 += 8) {
-      if (j0 + 8 < 64) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = (j0 + 8 + u) & 63;
-          gn[u] = go_one(go_rsrc, ch * 4, __builtin_amdgcn_readlane(pack, j) & ~127);
-          an[u] = par[2 * j];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);               // keep the requests above ahead of the updates below
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int line = __builtin_amdgcn_readlane(pack, j0 + u) & 127;
-        if (line != cur) {                             // wave-uniform: a new run -- park the finished one in the window
-          if (cur >= 0) {
-            float* p = wq + cur * kCh;
-            p[0] += acc_t;
-            p[kWin * kCh] += acc_b;
-          }
-          cur = line; acc_t = 0.f; acc_b = 0.f;
-        }
-        acc_t += a[u].x * g[u];
-        acc_b += a[u].y * g[u];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
-    }
-  }
-  if (cur >= 0) {
-    float* p = wq + cur * kCh;
-    p[0] += acc_t;
-    p[kWin * kCh] += acc_b;
-  }
-  __builtin_amdgcn_wave_barrier();
   // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
   float* gv = grad_value + (((int64_t)b * Nv + lsi[l]) * H + h) * kCh + ch;
   for (int i = half; i < kWinLines; i += 2) {
@@ -1024,7 +873,7 @@ inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
   // a level of h x w pixels has (h/k+1)(w/k+1) <= hw/k^2 + (h+w)/k + 1 <= hw (1+k)/k^2 + 2 tiles (h + w <= hw + 1)
   p.tiles_bound = ((int64_t)Nv * (1 + kTile)) / (kTile * kTile) + 2 * L + 1;
   p.nbins_bound = (int64_t)B * H * p.tiles_bound;
-  p.max_chunks = p.n_samples / kSegChunk + p.nbins_bound;      // sized for the smaller of the two chunk sizes
+  p.max_chunks = p.n_samples / kChunk + p.nbins_bound;
   p.off_cursor = (sizeof(int) * (size_t)p.nbins_bound + 15) & ~(size_t)15;      // [counts][cursor]: 16-byte aligned tables
   p.off_chunks = 2 * p.off_cursor;
   p.off_desc = p.off_chunks + 16;
@@ -1043,7 +892,6 @@ inline bool msda_bad(int B, int Nv, int H, int C, int Nq, int L, int P) {
 }
 
 int g_head_major = 1;          // item order of the gather kernels (see ItemMap); vidar_msda_set_item_order
-int g_tile_variant = 1;        // accumulate kernel of the binned backward: 1 line-sorted (default), 0 read-modify-write per sample
 
 // The gather kernels' records take 1 KiB x (L*P + 1) of dynamic LDS: past 64 KiB (L*P >= 63) a kernel must opt in.
 // Returns false when the device cannot provide it (the caller answers VIDAR_ERR_BAD_ARG instead of a failed launch).
@@ -1071,12 +919,6 @@ extern "C" {
 int vidar_msda_set_item_order(int head_major) {
   const int prev = g_head_major;
   g_head_major = head_major ? 1 : 0;
-  return prev;
-}
-
-int vidar_msda_set_tile_variant(int variant) {
-  const int prev = g_tile_variant;
-  if (variant == 0 || variant == 1) g_tile_variant = variant;
   return prev;
 }
 
@@ -1130,22 +972,14 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     hipLaunchKernelGGL(msda_bin_kernel<false>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
                        counts, rec, H, Nq, L, P);
     const int nslabs = (int)((p.nbins_bound + kScanSlab - 1) / kScanSlab);
-    const int seg = g_tile_variant;
     hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(nslabs), dim3(kScanThreads), 0, s, spatial_shapes, counts, cursor, desc,
-                       n_chunks, B, H, L, seg ? kSegChunk : kChunk);
+                       n_chunks, B, H, L);
     hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
                        cursor, rec, H, Nq, L, P);
-    if (seg) {
-      const int64_t bound = p.n_samples / kSegChunk + p.nbins_bound;
-      hipLaunchKernelGGL(msda_bwd_tile_seg_kernel, dim3((unsigned)((bound + kSegWaves - 1) / kSegWaves)), dim3(64 * kSegWaves), 0,
-                         s, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc,
-                         n_chunks, Nv, H, L, P, (int)(n_items * kCh * 4));
-    } else {
-      const int64_t bound = p.n_samples / kChunk + p.nbins_bound;
-      hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3((unsigned)((bound + kTWaves - 1) / kTWaves)), dim3(64 * kTWaves), 0, s,
-                         spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc,
-                         n_chunks, Nv, H, L, P, (int)(n_items * kCh * 4));
-    }
+    const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
+    hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
+                       Nv, H, L, P, (int)(n_items * kCh * 4));
     int nblocks, grid;
     gather_grid(n_items, H, nblocks, grid);
     const size_t lds = rec_lds_bytes(L * P);
