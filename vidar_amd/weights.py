@@ -58,7 +58,7 @@ def apply_trained_like(model, batch, seed=0, dcn_offset_px=1.5, dcn_mask_logit=1
         sd = float(x_out.float().std())
         if not (sd > 0.0) or sd != sd:
             return None
-        w[rows] *= target / sd
+        w.data[rows] *= target / sd              # .data: the model's forward may switch autograd back on around the hook
         return sd
 
     # --- DCNv2: conv_offset [27, C, 3, 3] -> channels 0..17 offsets (pixels), 18..26 mask logits -----------------
@@ -76,7 +76,8 @@ def apply_trained_like(model, batch, seed=0, dcn_offset_px=1.5, dcn_mask_logit=1
             if todo.pop(name, None) is None:
                 return
             co = mod.conv_offset
-            out = F.conv2d(args[0].float(), co.weight.float(), None, co.stride, co.padding, co.dilation)
+            with torch.no_grad():
+                out = F.conv2d(args[0].float(), co.weight.float(), None, co.stride, co.padding, co.dilation)
             a = scale_rows(co.weight, slice(0, 2 * k2), out[:, :2 * k2], dcn_offset_px)
             m = scale_rows(co.weight, slice(2 * k2, 3 * k2), out[:, 2 * k2:], dcn_mask_logit)
             if a is None or m is None:
@@ -98,7 +99,8 @@ def apply_trained_like(model, batch, seed=0, dcn_offset_px=1.5, dcn_mask_logit=1
             def pre(mod, args, key=key, target=target):
                 if todo.pop(key, None) is None:
                     return
-                out = F.linear(args[0].float(), mod.weight.float())
+                with torch.no_grad():
+                    out = F.linear(args[0].float(), mod.weight.float())
                 if scale_rows(mod.weight, slice(None), out, target) is None:
                     report["uncalibrated"].append(key)
                 elif key.endswith("sampling_offsets"):
