@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-backbone", action="store_true",
                     help="feed FPN pyramids instead of images (hot path of SURVEY 8a only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ddp-ab", action="store_true",
+                    help="N > 1: skip the short records of the other gradient-exchange modes (flat / flat2 / torch, `ddp_ab`)")
     ap.add_argument("--cpu-baseline-step", action="store_true",
                     help="also time the oracle port of the WHOLE step on a bounded sample (BEV 50x50; round-2 leg)")
     ap.add_argument("--weights", default="trained_like",
@@ -550,12 +552,30 @@ def timed_steps(step, steps, warmup, grouped, cuda, after_warmup=None, markers=N
     return elapsed
 
 
+def allreduce_alone_ms(nbytes, dev, iters=5):
+    """the collective by itself: `iters` all-reduces of an fp32 buffer of the step's gradient bytes on an otherwise idle
+    device (HIP events around the batch), so that a record says how much of the step the exchange COULD cost when
+    nothing hides it -- next to the step times of the exchange modes (`ddp_ab`) this tells overlap from overhead"""
+    if not nbytes:
+        return None
+    buf = torch.zeros(max(1, nbytes // 4), device=dev)
+    dist.all_reduce(buf)
+    torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / iters
+
+
 def ddp_info(ddp, world):
     """what the gradient all-reduce moves per step (RCCL over xGMI): DDP's own bucket accounting.  With
     find_unused_parameters=False torch starts with ONE bucket and rebuilds the buckets after the first step in
     the order gradients became ready -- `rebuilt_bucket_bytes` is what overlaps with backward from step 2 on."""
     if hasattr(ddp, "logging_data"):                                 # vidar_amd.train.FlatAllReduce (the default)
-        return dict(ddp.logging_data(), backend=dist.get_backend(), world_size=world)
+        return dict(ddp.logging_data(), backend=dist.get_backend(), world_size=world, rccl_ranks=dist.get_world_size())
     if not hasattr(ddp, "_get_ddp_logging_data"):
         return None
     try:
@@ -566,7 +586,8 @@ def ddp_info(ddp, world):
         return {"buckets": len(live), "bucket_bytes": live, "allreduce_bytes_per_step": sum(live),
                 "initial_bucket_bytes": sizes, "rebuilt_bucket_bytes": rebuilt,
                 "has_rebuilt_buckets": bool(info.get("has_rebuilt_buckets", 0)), "bucket_cap_mb": 100,
-                "backend": dist.get_backend(), "world_size": world}
+                "mode": "torch DistributedDataParallel (bucketed, overlapped by the reducer)",
+                "backend": dist.get_backend(), "world_size": world, "rccl_ranks": dist.get_world_size()}
     except Exception as e:                                           # logging only, never fail the bench
         return {"error": str(e)[:100]}
 
@@ -588,14 +609,15 @@ def make_batch(cfg, args, rank, dev, spg=None):
 
 
 def run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, gemm_mode=None, tune=True,
-               weights=None):
+               weights=None, ddp_mode=None):
     """build the model of one named config, time `steps` training steps -> dict(elapsed, ops, ddp, cfg, peak_mem_gb)"""
     from vidar_amd import gemm as G
     prev = G.set_mode(gemm_mode or G.mode())
     try:
         torch.cuda.reset_peak_memory_stats(dev)
         t0 = time.perf_counter()
-        r = _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg, tune, weights or args.weights)
+        r = _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg, tune, weights or args.weights,
+                        ddp_mode)
         if rank == 0:
             print(f"[bench] {name} spg={spg or args.samples_per_gpu} gemm={G.mode()} weights={r['weights']['mode']}: "
                   f"{r['elapsed'] / steps * 1e3:.1f} ms/step "
@@ -614,7 +636,8 @@ GEMM_DTYPE = {"lib": "f32", "auto": "f32", "f32": "f32",
               "bf16x3": "f32 storage, bf16x3 MFMA products (16-bit significand >= TF32), f32 accumulate"}
 
 
-def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, tune=True, weights="init"):
+def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers, spg=None, tune=True, weights="init",
+                ddp_mode=None):
     from vidar_amd import gemm_tuning
     from vidar_amd import train as T
     from vidar_amd import weights as W
@@ -629,7 +652,7 @@ def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers
     # the weight state is set BEFORE the data-parallel wrapper broadcasts rank 0's parameters: every rank then times the
     # same model (the calibration pass of `trained_like` sees each rank's own batch)
     wrep = W.prepare(model, batch, weights) if weights in W.MODES else W.prepare(model, batch, checkpoint=weights)
-    ddp = T.wrap_ddp(model, local)
+    ddp = T.wrap_ddp(model, local, mode=ddp_mode)
     opt = T.build_optimizer(model)
     grouped = dist.is_available() and dist.is_initialized()
 
@@ -654,6 +677,8 @@ def _run_config(name, args, rank, local, world, dev, steps, warmup, with_markers
     info = ddp_info(ddp, world) if grouped else None
     del batch, ddp, opt, model
     torch.cuda.empty_cache()
+    if info and "allreduce_bytes_per_step" in info:
+        info["allreduce_alone_ms"] = allreduce_alone_ms(info["allreduce_bytes_per_step"], dev)
     return dict(elapsed=elapsed, ops=ops, ddp=info, cfg=cfg, weights=wrep)
 
 
@@ -694,6 +719,23 @@ def main():
     main_run = run_config(args.config, args, rank, local, world, dev, args.steps, args.warmup, with_markers=True,
                           gemm_mode=args.gemm)
     elapsed, ops, cfg = main_run["elapsed"], main_run["ops"], main_run["cfg"]
+    # the gradient-exchange modes side by side on the headline config, whenever a process group exists: which of them is
+    # fastest at N ranks is decided by THIS measurement (on one rank they only differ by host overhead)
+    ddp_ab = []
+    if grouped and not args.no_ddp_ab:
+        main_mode = os.environ.get("VIDAR_DDP", "flat")
+        ddp_ab.append({"mode": main_mode, "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, "headline": True})
+        for mode in T.DDP_MODES:
+            if mode == main_mode:
+                continue
+            try:
+                r = run_config(args.config, args, rank, local, world, dev, args.extra_steps, args.extra_warmup,
+                               with_markers=False, gemm_mode=args.gemm, tune=False, ddp_mode=mode)
+                ddp_ab.append({"mode": mode, "ms_per_step": r["elapsed"] / args.extra_steps * 1e3, "steps": args.extra_steps,
+                               "ddp": r["ddp"]})
+            except Exception as e:                                          # noqa: BLE001
+                ddp_ab.append({"mode": mode, "error": f"{type(e).__name__}: {e}"[:200]})
+                torch.cuda.empty_cache()
     extras = []
     t_extras = time.perf_counter()
     for entry in [c for c in args.extra_configs.split(",") if c]:
@@ -801,6 +843,8 @@ def main():
             out["configs"] = extras
         if main_run["ddp"]:
             out["ddp"] = main_run["ddp"]
+        if ddp_ab:
+            out["ddp_ab"] = ddp_ab
         # the two auxiliary legs run after the timed region; a failure in one of them is reported in the line
         # (and on stderr) instead of costing the measured throughput its record
         if world == 1 and not args.no_kernel_rooflines and not grouped:

@@ -14,7 +14,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, mode):
+def _worker(rank, world, port, out, mode, with_backbone=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VIDAR_DDP=mode)
     import sys
@@ -29,12 +29,22 @@ def _worker(rank, world, port, out, mode):
     torch.manual_seed(7)                       # same weights everywhere
     np.random.seed(rank)
     cfg, batch = _small_batch("vidar_1_8_nusc_1future", seed=10 + rank)   # different sample per rank
+    if with_backbone:
+        from test_weights_cpu import _tiny_image_batch
+        cfg, batch = _tiny_image_batch()
+        batch["img"] = batch["img"] + 0.1 * rank
     model = T.build_model(cfg).train()
     ddp = T.wrap_ddp(model, l)
     assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel if mode == "torch" else T.FlatAllReduce)
     opt = T.build_optimizer(model)
     with cpu_ops.patched():
         loss, _ = T.train_step(ddp, opt, batch)
+    if mode.startswith("flat"):
+        info = ddp.logging_data()
+        assert info["buckets"] == (2 if mode == "flat2" else 1) and all(b > 0 for b in info["bucket_bytes"])
+        assert info["allreduce_bytes_per_step"] == sum(info["bucket_bytes"])
+        if mode == "flat2":                      # the early buffer really left from inside backward, not from the fallback
+            assert info["early_bucket_overlapped"] is with_backbone
     # after the all-reduced step the replicas are still identical although the samples differ
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
@@ -44,11 +54,11 @@ def _worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-def _run(mode):
+def _run(mode, with_backbone=False):
     mgr = mp.Manager()
     out = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, mode, with_backbone), nprocs=2, join=True)
     assert set(out.keys()) == {0, 1}
     assert out[0][0] != out[1][0], "ranks must see different samples"
     assert out[0][1] == 0.0, "parameters diverged across ranks after the data-parallel step"
@@ -61,6 +71,14 @@ def test_ddp_two_ranks_gloo():
     a = _run("flat")
     b = _run("torch")
     assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (a, b)
+
+
+def test_flat2_overlapped_exchange_gives_the_same_update():
+    """VIDAR_DDP=flat2 (backbone + neck gradients all-reduced asynchronously as soon as the last of them has arrived,
+    the rest after backward) on the image-in step: replicas stay identical and the update equals the one-buffer form"""
+    a = _run("flat", with_backbone=True)
+    b = _run("flat2", with_backbone=True)
+    assert a == b, (a, b)                         # the same sums in the same rank order
 
 
 def _unused_worker(rank, world, port, out):

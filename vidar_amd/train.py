@@ -85,22 +85,79 @@ class FlatAllReduce(torch.nn.Module):
     hooks are 0.6 ms and the collective itself 0.09 ms -- the rest is the per-parameter bucket traffic of a reducer that
     overlaps the all-reduce with backward (334 gradients copied into bucket views one launch at a time inside a
     backward pass that is GPU-bound), i.e. the overlap machinery costs more than the 250 MB all-reduce it hides (~2 ms
-    over 8 x xGMI, < 1 % of a 350 ms step).  So: no hooks, no buckets -- after backward the gradients are gathered into
+    over 8 x xGMI, < 1 % of a 350 ms step).  So: no buckets -- after backward the gradients are gathered into
     one flat buffer (one batched copy), pre-divided by the world size, all-reduced (RCCL over xGMI) and handed back to
     the parameters as views of that buffer.  Same result as DDP's averaged gradients (sum of g / world in rank order
-    is what both compute).  `VIDAR_DDP=torch` selects torch's DistributedDataParallel instead."""
+    is what both compute).  `VIDAR_DDP=torch` selects torch's DistributedDataParallel instead.
 
-    def __init__(self, module):
+    mode "flat2" (`VIDAR_DDP=flat2`): TWO flat buffers.  The image backbone + neck hold 2/3 of the gradient bytes and
+    their backward finishes in the MIDDLE of the step's backward pass: forward_train computes the history BEV (whose
+    encoder pass is back-propagated, detectors/vidar.py:273-287) BEFORE the current frame's backbone, so autograd
+    runs head -> decoder -> encoder -> backbone -> history encoder.  A post-accumulate hook per backbone / neck parameter
+    counts the gradients in; when the last one has arrived their flat buffer is all-reduced ASYNCHRONOUSLY (RCCL runs the
+    collective on its own stream) under the history encoder's backward, and only the remaining third is exchanged after
+    backward.  Same sums in the same rank order -> the same update as "flat" (tests/test_ddp_cpu.py).  Which of flat /
+    flat2 / torch is fastest at 8 ranks is a measurement bench.py makes itself whenever it runs on more than one rank
+    (`ddp_ab` in its line); on one rank the three differ only by their host overhead."""
+
+    def __init__(self, module, mode="flat"):
         super().__init__()
+        assert mode in ("flat", "flat2")
         self.module = module
+        self.mode = mode
         self.world = dist.get_world_size()
         self.last_bytes = 0
+        self.early_bytes = 0
+        self.early_was_async = False
         with torch.no_grad():                      # every rank starts from rank 0's weights and buffers (DDP does the same)
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0)
+        self._early, self._early_ids, self._pending, self._work = [], set(), 0, None
+        if mode == "flat2":
+            self._early = [p for n, p in module.named_parameters()
+                           if p.requires_grad and n.startswith(("img_backbone.", "img_neck."))]
+            self._early_ids = {id(p) for p in self._early}
+            for p in self._early:
+                p.register_post_accumulate_grad_hook(self._early_grad_arrived)
 
     def forward(self, *args, **kwargs):
+        self._pending = len(self._early) if torch.is_grad_enabled() else 0
+        self._work = None
         return self.module(*args, **kwargs)
+
+    def _early_grad_arrived(self, p):
+        if self._pending <= 0:
+            return
+        self._pending -= 1
+        if self._pending == 0:
+            self._work = self._start(self._early, async_op=True)
+
+    def _start(self, params, async_op):
+        """flat buffer of `params`' gradients (+ one "this rank produced a gradient" float per parameter) -> all-reduce"""
+        have = [p.grad is not None for p in params]
+        ref = next((p.grad for p in params if p.grad is not None), params[0])
+        mask = torch.tensor([1.0 if h else 0.0 for h in have], dtype=ref.dtype, device=ref.device)
+        flat = torch.cat([(p.grad if h else torch.zeros_like(p)).reshape(-1) for p, h in zip(params, have)] + [mask])
+        n_grad = flat.numel() - len(params)
+        if self.world > 1:
+            flat[:n_grad].div_(self.world)
+        work = dist.all_reduce(flat, async_op=async_op)
+        return params, have, flat, n_grad, work
+
+    def _finish(self, started):
+        params, have, flat, n_grad, work = started
+        if work is not None:
+            work.wait()
+        nobody = set()
+        if not all(have):
+            total = flat[n_grad:].cpu()
+            nobody = {i for i, h in enumerate(have) if not h and float(total[i]) == 0.0}
+        off = 0
+        for i, p in enumerate(params):
+            n = p.numel()
+            p.grad = None if i in nobody else flat[off:off + n].view_as(p)
+            off += n
+        return flat.numel() * flat.element_size()
 
     def reduce_gradients(self):
         # every rank must contribute the same layout: all trainable parameters in module order, a parameter that got
@@ -113,37 +170,41 @@ class FlatAllReduce(torch.nn.Module):
         params = [p for p in self.module.parameters() if p.requires_grad]
         if not params:
             return
-        have = [p.grad is not None for p in params]
-        ref = next((p.grad for p in params if p.grad is not None), params[0])
-        mask = torch.tensor([1.0 if h else 0.0 for h in have], dtype=ref.dtype, device=ref.device)
-        flat = torch.cat([(p.grad if h else torch.zeros_like(p)).reshape(-1) for p, h in zip(params, have)] + [mask])
-        n_grad = flat.numel() - len(params)
-        if self.world > 1:
-            flat[:n_grad].div_(self.world)
-        dist.all_reduce(flat)
-        nobody = set()
-        if not all(have):
-            total = flat[n_grad:].cpu()
-            nobody = {i for i, h in enumerate(have) if not h and float(total[i]) == 0.0}
-        off = 0
-        for i, p in enumerate(params):
-            n = p.numel()
-            p.grad = None if i in nobody else flat[off:off + n].view_as(p)
-            off += n
-        self.last_bytes = flat.numel() * flat.element_size()
+        early = self._work
+        self.early_was_async = early is not None
+        if self._early and early is None:
+            # a backbone / neck gradient never arrived on this rank (its hook count did not run out): exchange the early
+            # buffer now -- every rank issues the same two collectives in the same order either way
+            early = self._start(self._early, async_op=False)
+        late = self._start([p for p in params if id(p) not in self._early_ids], async_op=False)
+        self.early_bytes = self._finish(early) if early is not None else 0
+        self.last_bytes = self._finish(late) + self.early_bytes
+        self._work, self._pending = None, 0
 
     def logging_data(self):
+        if self.mode == "flat2":
+            return {"mode": "two flat all-reduces: backbone + neck asynchronously under the history encoder's backward, the "
+                            "rest after backward (vidar_amd.train.FlatAllReduce, flat2)", "buckets": 2,
+                    "bucket_bytes": [self.early_bytes, self.last_bytes - self.early_bytes],
+                    "early_bucket_overlapped": self.early_was_async, "allreduce_bytes_per_step": self.last_bytes}
         return {"mode": "flat all-reduce after backward (vidar_amd.train.FlatAllReduce)", "buckets": 1,
                 "bucket_bytes": [self.last_bytes], "allreduce_bytes_per_step": self.last_bytes}
 
 
-def wrap_ddp(model, local_rank, bucket_cap_mb=100):
+DDP_MODES = ("flat", "flat2", "torch")
+
+
+def wrap_ddp(model, local_rank, bucket_cap_mb=100, mode=None):
+    """mode: one of DDP_MODES (default: $VIDAR_DDP, else "flat")"""
     if not (dist.is_available() and dist.is_initialized()):
         return model
     if dist.get_world_size() == 1 and os.environ.get("VIDAR_FORCE_DDP") != "1":
         return model
-    if os.environ.get("VIDAR_DDP", "flat") != "torch":
-        return FlatAllReduce(model)
+    mode = mode or os.environ.get("VIDAR_DDP", "flat")
+    if mode not in DDP_MODES:
+        raise ValueError(f"gradient exchange {mode!r}: expected one of {DDP_MODES}")
+    if mode != "torch":
+        return FlatAllReduce(model, mode)
     kw = dict(broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
               find_unused_parameters=False)
     if torch.cuda.is_available():
