@@ -27,7 +27,9 @@ def test_full_size_forward_matches_the_oracle_routed_forward():
                             num_cams=cfg["num_cams"], img_hw=cfg["img_hw"])
     g = torch.Generator().manual_seed(2)
     img = torch.randn(1, 2, cfg["num_cams"], 3, *cfg["img_hw"], generator=g)
-    batch = dict(img=img, img_metas=[metas], gt_points=[torch.from_numpy(gt)])
+    import copy
+    # (own metas per pass: the detector parks per-step device tensors -- the SCA plan -- in the meta dictionaries)
+    batch = dict(img=img, img_metas=[copy.deepcopy(metas)], gt_points=[torch.from_numpy(gt)])
     model = T.build_model(cfg)
     for m in model.modules():
         if hasattr(m, "random_drop_prev_rate"):
@@ -40,7 +42,7 @@ def test_full_size_forward_matches_the_oracle_routed_forward():
     dev = dict(img=img.cuda(), img_metas=[metas], gt_points=[torch.from_numpy(gt).cuda()])
     # trained-like weights (per-pixel DCNv2 offsets, per-query attention offsets): the harder sampling pattern, and
     # off the bilinear kinks of the initial integer rings
-    rep = W.apply_trained_like(model, dev, seed=1)
+    rep = W.apply_trained_like(model, dict(dev, img_metas=[copy.deepcopy(metas)]), seed=1)
     assert not rep["uncalibrated"]
     with torch.no_grad():
         out = {k: float(v) for k, v in model(return_loss=True, **dev).items()}
