@@ -382,11 +382,6 @@ size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision,
  * order: results are bit-identical.  Returns the previous value. */
 int vidar_gemm_set_variant(int variant);
 
-/* A/B switch of the DCNv2 sampling kernels.  bit 0 (default on): im2col of 3x3 / stride 1 / dilation 1 layers stages the
- * input window of an 8 x 32 pixel tile (+ a 6-pixel halo for the learned offsets) in LDS and gathers from there, samples
- * that leave the window take the global path; 0 = the global pair-load kernel of rounds 3-5 everywhere.  Results are the
- * same fp32 products in the same order.  Values outside 0..1 are ignored.  Returns the previous value. */
-int vidar_dcn_set_variant(int variant);
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
                          int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
                          int dil, void* stream);

@@ -155,30 +155,3 @@ def test_fused_stem_pool_matches_two_kernel_path(shape):
     assert out is not None and out.shape == ref.shape
     assert torch.equal(out, ref)
     assert stem_bn_relu_pool(x.requires_grad_(), bn) is None           # gradients needed -> the caller's two-kernel path
-
-
-@pytest.mark.parametrize("N,C,H,W,std", [(2, 40, 58, 100, 1.5), (1, 33, 29, 50, 4.0), (1, 8, 9, 70, 8.0), (3, 5, 7, 3, 1.0),
-                                         (1, 64, 116, 200, 2.0)])
-def test_im2col_lds_window_equals_global_pair_loads(N, C, H, W, std):
-    """the two im2col kernels of 3x3 / stride 1 layers (vidar_dcn_set_variant): LDS window + global path for the samples
-    that leave it (std 4 / 8 px: many do; NaN and far-outside offsets included) against global pair loads everywhere --
-    the same four products per column element, so only the order of two multiplications differs"""
-    from vidar_amd._lib import check, lib, ptr, stream_of
-    g = torch.Generator().manual_seed(C + H)
-    x = torch.randn(N, C, H, W, generator=g).cuda()
-    off = torch.randn(N, 18, H, W, generator=g) * std
-    off[0, 4, 0, :] = float("nan"); off[0, 7, -1, -1] = 1e4; off[0, 0, :, 0] = -3.0 * std
-    off = off.cuda()
-    mask = torch.rand(N, 9, H, W, generator=g).cuda()
-    outs = []
-    for variant in (1, 0):
-        prev = lib().vidar_dcn_set_variant(variant)
-        try:
-            cols = torch.full((N, C * 9, H * W), float("nan"), device="cuda")
-            check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(off), ptr(mask), ptr(cols), N, C, H, W, H, W, 3, 3, 1, 1, 1,
-                                             stream_of(x)), "dcn_im2col")
-            outs.append(cols)
-        finally:
-            lib().vidar_dcn_set_variant(prev)
-    assert torch.isfinite(outs[0]).all() and torch.isfinite(outs[1]).all()       # every element written, NaN offsets -> 0
-    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-6)

@@ -204,115 +204,6 @@ __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __res
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// im2col, LDS-window form (round 6; 3x3 / stride 1 / dilation 1 -- 24 of the backbone's 26 DCNv2 layers).
-// With trained offsets (~N(0, (1.5 px)^2), the state the step is measured in since round 6) the pair-load kernel above
-// degrades: neighbouring lanes no longer read neighbouring pairs, a wave instruction touches 10-20 cache lines for 512
-// useful bytes and the kernel sits on the texture-address path (0.33 vs 0.25 ms per call; the column write it exists
-// for would take 0.07 ms).  Here a workgroup owns an 8 x 32 tile of output pixels and a group of channels:
-//   * the nine footprints of every pixel (index into the window, four corner weights x mask) are computed ONCE and kept
-//     in registers for all channels of the workgroup (the kernel above recomputes them per 16 channels);
-//   * per round of kLC channels the input window of the tile -- tile + the 3x3 reach + a halo of kHalo pixels for the
-//     learned offsets, zero outside the image -- is copied into LDS with coalesced row segments, and the gather reads LDS
-//     (ds_read2_b32 pairs at a compile-time row pitch; the zero border makes the edge cases of the bilinear kernel
-//     disappear: a corner outside the image simply reads 0);
-//   * a sample whose footprint leaves the window (|offset| >= kHalo) is rare and takes the global pair-load path
-//     afterwards, for that (pixel, tap) only.
-// ---------------------------------------------------------------------------------------------
-constexpr int kTH = 8, kTW = 32;              // output tile (one thread per pixel)
-constexpr int kHalo = 6;                      // reach of the learned offsets served from LDS, pixels
-constexpr int kWH = (kTH - 1) + 2 + 2 * kHalo + 2;                 // 23 window rows   (3x3, stride 1, dilation 1)
-constexpr int kWW = ((kTW - 1) + 2 + 2 * kHalo + 2 + 3) / 4 * 4;   // 48 window columns (47 needed)
-constexpr int kLC = 8;                        // channels per LDS round
-constexpr int kWGC = 32;                      // channels per workgroup (kWGC / kLC rounds)
-
-__global__ __launch_bounds__(kTH * kTW) void dcn_im2col_lds_kernel(const float* __restrict__ x,
-                                                                   const float* __restrict__ offset,
-                                                                   const float* __restrict__ mask,
-                                                                   float* __restrict__ cols, Conv g, int tiles_x) {
-  __shared__ float s_win[kLC * kWH * kWW];
-  constexpr int K = 9;
-  const int P = g.Ho * g.Wo;
-  const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-  const int n = blockIdx.z, cw0 = blockIdx.y * kWGC;
-  const int ry = threadIdx.x / kTW, rx = threadIdx.x % kTW;
-  const int py = tyi * kTH + ry, px = txi * kTW + rx;
-  const bool live = py < g.Ho && px < g.Wo;
-  const int p = live ? py * g.Wo + px : 0;
-  const int wy0 = tyi * kTH - g.pad - kHalo, wx0 = txi * kTW - g.pad - kHalo;     // image coordinates of window (0, 0)
-  // footprints: once per workgroup
-  int top[K];
-  float w00[K], w01[K], w10[K], w11[K];
-  unsigned outside = 0;                       // taps of this pixel whose footprint leaves the window
-  {
-    const float* off_n = offset + (size_t)n * 2 * K * P + p;
-    const float* msk_n = mask + (size_t)n * K * P + p;
-#pragma unroll
-    for (int t = 0; t < K; ++t) {
-      const int i = t / 3, j = t - i * 3;
-      const float h = py - g.pad + i + off_n[(size_t)(2 * t) * P], w = px - g.pad + j + off_n[(size_t)(2 * t + 1) * P];
-      const float m = msk_n[(size_t)t * P];
-      const bool in = live && h > -1.f && w > -1.f && h < g.H && w < g.W;          // (false for NaN offsets)
-      const int h0 = (int)floorf(h), w0 = (int)floorf(w);
-      const float lh = h - h0, lw = w - w0;
-      const int r = h0 - wy0, c = w0 - wx0;
-      const bool inwin = r >= 0 && r + 1 < kWH && c >= 0 && c + 1 < kWW;
-      const bool use = in && inwin;
-      if (in && !inwin) outside |= 1u << t;
-      top[t] = use ? r * kWW + c : 0;
-      // a sample outside the image (or NaN) contributes nothing: select, not a product with 0
-      w00[t] = use ? (1.f - lh) * (1.f - lw) * m : 0.f; w01[t] = use ? (1.f - lh) * lw * m : 0.f;
-      w10[t] = use ? lh * (1.f - lw) * m : 0.f;         w11[t] = use ? lh * lw * m : 0.f;
-    }
-  }
-  const size_t plane = (size_t)g.H * g.W, KP = (size_t)K * P;
-  for (int c0 = cw0; c0 < min(cw0 + kWGC, g.C); c0 += kLC) {
-    const int nc = min(kLC, g.C - c0);
-    __syncthreads();                          // the previous round's reads are done
-    for (int e = threadIdx.x; e < kLC * kWH * kWW; e += kTH * kTW) {
-      const int c = e / (kWH * kWW), rem = e - c * (kWH * kWW);
-      const int r = rem / kWW, col = rem - r * kWW;
-      const int gy = wy0 + r, gx = wx0 + col;
-      float v = 0.f;
-      if (c < nc && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) v = x[((size_t)n * g.C + c0 + c) * plane + (size_t)gy * g.W + gx];
-      s_win[e] = v;
-    }
-    __syncthreads();
-    if (live) {
-      float* out = cols + ((size_t)n * g.C + c0) * KP + p;
-#pragma unroll
-      for (int c = 0; c < kLC; ++c) {
-        if (c < nc) {
-          const float* sw = s_win + c * (kWH * kWW);
-#pragma unroll
-          for (int t = 0; t < K; ++t) {
-            const float* q = sw + top[t];
-            const float v = w00[t] * q[0] + w01[t] * q[1] + w10[t] * q[kWW] + w11[t] * q[kWW + 1];
-            __builtin_nontemporal_store(v, out + (size_t)c * KP + (size_t)t * P);
-          }
-        }
-      }
-    }
-  }
-  if (outside) {                              // rare: |offset| >= kHalo -- the global pair-load form for these taps
-    const float* off_n = offset + (size_t)n * 2 * K * P + p;
-    const float* msk_n = mask + (size_t)n * K * P + p;
-    for (int t = 0; t < K; ++t) {
-      if (!(outside >> t & 1)) continue;
-      const int i = t / 3, j = t - i * 3;
-      const TapFoot f = tap_foot(py - g.pad + i + off_n[(size_t)(2 * t) * P], px - g.pad + j + off_n[(size_t)(2 * t + 1) * P],
-                                 msk_n[(size_t)t * P], g);
-      for (int c = cw0; c < min(cw0 + kWGC, g.C); ++c) {
-        const char* pl = reinterpret_cast<const char*>(x + ((size_t)n * g.C + c) * plane);
-        const pair_t a = *reinterpret_cast<const pair_t*>(pl + f.top), b = *reinterpret_cast<const pair_t*>(pl + f.bot);
-        cols[((size_t)n * g.C + c) * KP + (size_t)t * P + p] = f.wt0 * a.x + f.wt1 * a.y + f.wb0 * b.x + f.wb1 * b.y;
-      }
-    }
-  }
-}
-
-int g_dcn_variant = 1;         // bit 0: im2col through the LDS window kernel where it applies (vidar_dcn_set_variant)
-
 // grad wrt input: scatter grad_cols * mask * corner weights (atomics); grid as im2col.  Lanes are
 // neighbouring pixels, so a wave instruction touches only 2-3 lines (atomics cost per instruction x line).
 __global__ __launch_bounds__(256) void dcn_col2im_kernel(const float* __restrict__ grad_cols,
@@ -550,12 +441,6 @@ inline bool dcn_bad(int N, const Conv& g) {
 
 extern "C" {
 
-int vidar_dcn_set_variant(int variant) {
-  const int prev = g_dcn_variant;
-  if (variant >= 0 && variant <= 1) g_dcn_variant = variant;
-  return prev;
-}
-
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
                          int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
                          int dil, void* stream) {
@@ -564,11 +449,7 @@ int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask,
   if (dcn_bad(N, g)) return VIDAR_ERR_BAD_ARG;
   if (N == 0) return 0;
   if (kh * kw > kMaxTaps) return VIDAR_ERR_BAD_ARG;
-  if ((g_dcn_variant & 1) && kh == 3 && kw == 3 && stride == 1 && dil == 1 && W >= 2) {
-    const int tiles_x = (Wo + kTW - 1) / kTW, tiles_y = (Ho + kTH - 1) / kTH;
-    hipLaunchKernelGGL(dcn_im2col_lds_kernel, dim3(tiles_x * tiles_y, (C + kWGC - 1) / kWGC, N), dim3(kTH * kTW), 0,
-                       (hipStream_t)stream, x, offset, mask, cols, g, tiles_x);
-  } else if (W >= 2)
+  if (W >= 2)
     hipLaunchKernelGGL(dcn_im2col_pair_kernel, dim3((Ho * Wo + 255) / 256, (C + kCP - 1) / kCP, N), dim3(256),
                        0, (hipStream_t)stream, x, offset, mask, cols, g);
   else
