@@ -194,24 +194,31 @@ def bench_msda_sca_coherent(which):
 
 
 def bench_dcn(which):
-    """DCNv2 sampling kernels at the two backbone shapes (stage 3: 256 ch 58x100, stage 4: 512 ch 29x50),
-    12 images = the frames that carry gradients."""
+    """DCNv2 sampling kernels at the backbone shapes (stage 3: 256 ch 58x100 with the 6 gradient images / the 24 history
+    images, stage 4: 512 ch 29x50), offsets at init (0) and trained-like (N(0, (1.5 px)^2), vidar_amd/weights.py);
+    $VIDAR_KBENCH_DCN_STD overrides the list."""
+    import os
     from vidar_amd.plugin.backbones import dcn_col2im
     from vidar_amd._lib import lib, check, ptr, stream_of
     g = torch.Generator().manual_seed(0)
-    for N, C, H, W in ((12, 256, 58, 100), (12, 512, 29, 50)):
+    stds = [float(v) for v in os.environ.get("VIDAR_KBENCH_DCN_STD", "0,1.5").split(",")]
+    for N, C, H, W in ((6, 256, 58, 100), (24, 256, 58, 100), (6, 512, 29, 50)):
         x = torch.randn(N, C, H, W, generator=g).cuda()
-        off = (torch.randn(N, 18, H, W, generator=g) * 0.7).cuda()
         mask = torch.rand(N, 9, H, W, generator=g).cuda()
         gcols = torch.randn(N, C * 9, H * W, generator=g).cuda()
         cols = torch.empty_like(gcols)
-        ms = timeit(lambda: check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(off), ptr(mask), ptr(cols), N, C, H, W, H, W,
-                                                             3, 3, 1, 1, 1, stream_of(x)), "im2col"))
-        report(f"dcn_im2col N={N} C={C} {H}x{W}", ms, 4 * (x.numel() + cols.numel() + off.numel() + mask.numel()))
-        for gather in (False, True):
-            ms = timeit(lambda: dcn_col2im(gcols, x, off, mask, 3, 3, 1, 1, 1, H, W, gather=gather))
-            report(f"dcn_col2im N={N} C={C} {H}x{W} gather={gather}", ms,
-                   4 * (3 * x.numel() + gcols.numel() + 2 * off.numel() + 2 * mask.numel()))
+        for std in stds:
+            off = (torch.randn(N, 18, H, W, generator=g) * std).cuda()
+            tag = f"N={N} C={C} {H}x{W} offsets~{std}px"
+            ms = timeit(lambda: check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(off), ptr(mask), ptr(cols), N, C, H, W, H, W,
+                                                                 3, 3, 1, 1, 1, stream_of(x)), "im2col"))
+            report(f"dcn_im2col {tag}", ms, 4 * (x.numel() + cols.numel() + off.numel() + mask.numel()))
+            if N > 6:
+                continue                      # the history images carry no gradients
+            for gather in (False, True):
+                ms = timeit(lambda: dcn_col2im(gcols, x, off, mask, 3, 3, 1, 1, 1, H, W, gather=gather))
+                report(f"dcn_col2im {tag} gather={gather}", ms,
+                       4 * (3 * x.numel() + gcols.numel() + 2 * off.numel() + 2 * mask.numel()))
 
 
 def bench_affine(which):
