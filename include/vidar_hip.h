@@ -226,6 +226,15 @@ int vidar_drop_add_ln_bwd_f32(const float* grad_y, const float* sum_in, const fl
                               void* stream);
 size_t vidar_drop_add_ln_bwd_workspace_bytes(int64_t rows); /* scratch for the per-workgroup affine-gradient partials */
 
+/* y = dropout(relu(x)) and its backward, one pass each (csrc/norm_fuse.hip): the hidden activation of the FFN blocks
+ * (mmcv FFN [3P]: Linear -> ReLU -> Dropout -> Linear; custom_base_transformer_layer.py builds them from the configs'
+ * ffn_cfgs).  n elements (a multiple of 4), 0 <= p < 1; keeps element i iff hash(seed, i) >= p and scales it by
+ * 1 / (1 - p) (same hash as the fused LayerNorm tail; not torch's Philox stream: dropout noise has no parity contract,
+ * p = 0 is exact).  bwd: grad_x = y > 0 ? grad_y / (1 - p) : 0 -- y is the forward's OUTPUT, no mask is stored.
+ * x / y and grad_y / grad_x may alias. */
+int vidar_relu_drop_fwd_f32(const float* x, float* y, int64_t n, float p, uint32_t seed, void* stream);
+int vidar_relu_drop_bwd_f32(const float* grad_y, const float* y, float* grad_x, int64_t n, float p, void* stream);
+
 /* Column sums of a row-major [rows, cols] fp32 matrix: out[c] = sum_r x[r, c] -- the bias gradient of the Linear
  * layers on the path (what autograd computes with a generic `sum(0)` for every nn.Linear the reference's modules
  * own, e.g. temporal_self_attention.py:98-103, spatial_cross_attention.py:66, :244-248, vidar_decoder.py:358-363; mmcv FFN [3P]).  `out` [cols] is

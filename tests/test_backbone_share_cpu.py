@@ -39,3 +39,37 @@ def test_no_sharing_without_a_strided_conv1(monkeypatch):
     down = torch.nn.Sequential(B.Conv1x1(16, 32, 1, stride=2, bias=False), B.FrozenBN(32, False))
     blk = B.Bottleneck(16, 8, stride=2, downsample=down, style="pytorch")      # stride on conv2: conv1 reads all of x
     assert not blk._shares_subsample(torch.randn(1, 16, 4, 4))
+
+
+def test_identity_shortcut_gradient_accumulates_inside_the_convolutions_backward():
+    """Bottleneck with an identity shortcut: handing the block input through the first 1x1 convolution's Function
+    (backbones._Conv1x1Identity: grad_x = W^T grad_out + grad_identity in one GEMM) gives the values and gradients of
+    the plain autograd graph (conv1 and the shortcut as two consumers of x)"""
+    import torch
+    from vidar_amd.plugin import backbones as B
+    torch.manual_seed(0)
+    B.Conv1x1.any_device = True
+    try:
+        blk = B.Bottleneck(64, 16, style="pytorch").train()
+        assert blk.downsample is None
+        for p in blk.parameters():
+            p.requires_grad_(True)
+        x = torch.randn(2, 64, 6, 5, requires_grad=True)
+        outs = {}
+        for on in (True, False):
+            B._SHORTCUT_ACCUMULATE = on
+            y = blk(x)
+            g = torch.autograd.grad((y * torch.arange(y.numel()).view_as(y).float().sin()).sum(), [x] + list(blk.parameters()),
+                                    allow_unused=True)
+            outs[on] = (y.detach(), g)
+        B._SHORTCUT_ACCUMULATE = True
+        assert B.conv1x1_with_identity_ok(blk.conv1, x)                # the form really ran in the first pass
+        torch.testing.assert_close(outs[True][0], outs[False][0], rtol=0, atol=0)
+        for a, b in zip(outs[True][1], outs[False][1]):
+            if b is None:
+                assert a is None
+            else:
+                torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    finally:
+        B.Conv1x1.any_device = False
+        B._SHORTCUT_ACCUMULATE = True

@@ -100,3 +100,43 @@ def test_bricks_linear_gradients_equal_nn_linear():
     odd = Linear(256, 80).cuda()                               # 20 column groups: torch's own backward
     odd(x).sum().backward()
     assert torch.isfinite(odd.bias.grad).all()
+
+
+@pytest.mark.parametrize("shape,p", [((1, 40000, 512), 0.1), ((3, 17, 64), 0.5), ((2, 5, 8), 0.0)])
+def test_relu_dropout_one_pass_each_way(shape, p):
+    """dropout(relu(x)) of the FFN's hidden layer (csrc/norm_fuse.hip): values are relu(x) / (1 - p) or 0, the kept
+    fraction is 1 - p, the mask is a function of the seed, and the backward is exactly the forward's own mask"""
+    from vidar_amd.plugin.bricks import _ReluDropout
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(*shape, device="cuda", generator=g).requires_grad_(True)
+    y = _ReluDropout.apply(x, p, 12345)
+    r = torch.relu(x.detach())
+    kept = y.detach() != 0
+    assert not (kept & (r == 0)).any()
+    torch.testing.assert_close(y.detach()[kept], (r / (1.0 - p))[kept], rtol=1e-6, atol=0)
+    pos = r > 0
+    frac = float((kept & pos).sum()) / max(1, int(pos.sum()))
+    if p == 0.0:
+        assert frac == 1.0
+    elif x.numel() > 10000:
+        assert abs(frac - (1.0 - p)) < 0.01
+    assert torch.equal(_ReluDropout.apply(x, p, 12345), y) and (p == 0.0 or not torch.equal(_ReluDropout.apply(x, p, 777), y))
+    gy = torch.randn(*shape, device="cuda", generator=g)
+    gx, = torch.autograd.grad(y, x, gy)
+    torch.testing.assert_close(gx, torch.where(kept, gy / (1.0 - p), torch.zeros_like(gy)), rtol=1e-6, atol=0)
+
+
+def test_ffn_takes_the_fused_hidden_activation_in_training_and_torch_ops_in_eval():
+    from vidar_amd.plugin.bricks import FFN
+    torch.manual_seed(0)
+    ffn = FFN(256, 512, ffn_drop=0.1).cuda()
+    x = torch.randn(1, 300, 256, device="cuda", requires_grad=True)
+    ffn.eval()
+    ref = x + ffn.layers[1](torch.relu(ffn.layers[0][0](x)))
+    torch.testing.assert_close(ffn(x), ref, rtol=1e-5, atol=1e-5)
+    ffn.train()
+    torch.manual_seed(1); a = ffn(x)
+    torch.manual_seed(1); b = ffn(x)
+    assert torch.equal(a, b)                                  # reproducible under manual_seed
+    a.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and ffn.layers[0][0].weight.grad is not None

@@ -117,6 +117,47 @@ class Linear(nn.Linear):
         return F.relu(y, inplace=True) if relu else y
 
 
+class _ReluDropout(torch.autograd.Function):
+    """dropout(relu(x), p) as one HIP pass each way (csrc/norm_fuse.hip: vidar_relu_drop_{fwd,bwd}_f32); the backward reads
+    the saved OUTPUT (which the next Linear saves anyway) instead of a mask."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        import ctypes
+        from .._lib import lib, check, ptr, stream_of
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib().vidar_relu_drop_fwd_f32(ptr(x), ptr(y), ctypes.c_int64(x.numel()), ctypes.c_float(p),
+                                            ctypes.c_uint32(seed), stream_of(x)), "relu_drop_fwd")
+        ctx.save_for_backward(y)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        from .._lib import lib, check, ptr, stream_of
+        y, = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        check(lib().vidar_relu_drop_bwd_f32(ptr(gy), ptr(y), ptr(gx), ctypes.c_int64(gy.numel()), ctypes.c_float(ctx.p),
+                                            stream_of(gy)), "relu_drop_bwd")
+        return gx, None, None
+
+
+def relu_dropout(linear, x, p, training):
+    """dropout(relu(linear(x)), p).  Training on CUDA fp32 with p > 0: ONE elementwise pass after the GEMM each way (the
+    ReLU is not handed to the Linear then, unless its GEMM epilogue does it for free); otherwise the torch ops."""
+    p = float(p) if training else 0.0
+    fused = (p > 0.0 and x.is_cuda and x.dtype == torch.float32 and linear.weight.dtype == torch.float32
+             and not torch.is_autocast_enabled() and linear.out_features % 4 == 0 and x.numel() > 0)
+    if not fused:
+        return F.dropout(linear(x, relu=True), p, training)
+    h = linear(x, relu=_gemm.own_kernels())            # (ReLU in the MFMA GEMM's epilogue costs nothing; it is idempotent)
+    seed = int(torch.randint(0, 1 << 31, (1,), dtype=torch.int64).item()) * 2 + 1     # CPU generator: no device sync
+    return _ReluDropout.apply(h, p, seed)
+
+
 @FEEDFORWARD_NETWORK.register_module()
 class FFN(nn.Module):
     """Linear -> act -> drop -> Linear -> drop, plus identity (x when none is given)."""
@@ -142,6 +183,9 @@ class FFN(nn.Module):
         """layers[:-1]; a (Linear, ReLU, Dropout) stage hands its ReLU to the Linear (GEMM epilogue on the MFMA path)"""
         for stage in self.layers[:-1]:
             if (isinstance(stage, nn.Sequential) and len(stage) == 3 and isinstance(stage[0], Linear)
+                    and isinstance(stage[1], nn.ReLU) and isinstance(stage[2], nn.Dropout)):
+                x = relu_dropout(stage[0], x, stage[2].p, self.training)
+            elif (isinstance(stage, nn.Sequential) and len(stage) == 3 and isinstance(stage[0], Linear)
                     and isinstance(stage[1], nn.ReLU)):
                 x = stage[2](stage[0](x, relu=True))
             else:
