@@ -103,10 +103,10 @@ int vidar_dvxlr_render_f32(const float* sigma, const float* origin, const float*
 
 /* dvxlr.get_grad_sigma(elementwise_mult, indices, tindex, sigma_like) -> [grad_sigma]
  * third_lib/dvxlr/dvxlr.cu:63-156.  L = elementwise_mult.size(2). grad_sigma zeroed by the call.
- * `workspace` (vidar_dvxlr_get_grad_sigma_workspace_bytes; the v1 call needs half of it): caller-owned device
+ * `workspace` (vidar_dvxlr_get_grad_sigma_workspace_bytes(.., volumes): 1 for this call, 2 for get_grad_sigma_v2): caller-owned device
  * scratch for 8 private copies of the gradient volume -- the rays of a frame share their first voxels, whose
  * atomics otherwise serialise (one frame of 30 000 rays took as long as five); NULL = add straight into grad_sigma. */
-size_t vidar_dvxlr_get_grad_sigma_workspace_bytes(int N, int T, int Z, int Y, int X);
+size_t vidar_dvxlr_get_grad_sigma_workspace_bytes(int N, int T, int Z, int Y, int X, int volumes /* 1: get_grad_sigma, 2: _v2 */);
 int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult /*[N,M,L]*/,
                                    const float* indices /*[N,M,L,3]*/, const float* tindex,
                                    float* grad_sigma /*[N,T,Z,Y,X]*/, int N, int M, int L, int T,
@@ -277,7 +277,7 @@ int vidar_sca_combine_f32(const float* src, const int32_t* slot_of, const float*
  * (vidar_latent_render_bwd_workspace_bytes, caller-owned scratch, 16-byte aligned) holds 8 private copies of the
  * gradient maps as for the ray ops below, NULL = add straight into the outputs.
  * ------------------------------------------------------------------------- */
-size_t vidar_latent_render_bwd_workspace_bytes(int bs, int H, int W, int Z);
+size_t vidar_latent_render_bwd_workspace_bytes(int bs, int H, int W, int Z, int maps /* 1: prob_bwd, 2: gather_bwd */);
 int vidar_latent_render_prob_fwd_f32(const float* occ, float* path_prob, int bs, int H, int W, int Z,
                                      int grid_num, float step, int act, void* stream);
 int vidar_latent_render_prob_bwd_f32(const float* occ, const float* grad_path_prob, float* grad_occ,
@@ -384,6 +384,8 @@ int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, in
                    int64_t strideR, int relu, int precision, int reduce, float* a_rowsum, void* workspace,
                    size_t workspace_bytes, void* stream);
 int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce);
+/* scratch of a reduced product: reduce = 1 the product alone (0 bytes when it is a single slab), reduce = 2 the product
+ * with the row sums of A (`a_rowsum`): slabs + one partial row per slab */
 size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce);
 /* A/B switch of the kernel's structure: 0 (default) = every wave does every job; 1 / 2 = wave-specialised workgroups
  * (4 staging waves + 4 matrix / epilogue waves, LDS double buffer, one LDS-only barrier per k-step), one / two per CU

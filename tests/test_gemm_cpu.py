@@ -75,8 +75,11 @@ def test_split_plan_fills_the_chip_and_is_bounded():
     s = L.vidar_gemm_splits(256, 256, 184950, 1, 1, 1)
     assert 64 <= s <= 256 and (184950 + s - 1) // s >= 4 * 32
     # s slabs of [M, N] + s partial rows of [M] for the optional row sums of A (the bias gradient that rides along)
-    assert L.vidar_gemm_workspace_bytes(256, 256, 184950, 1, 1, 1) == s * (256 * 256 + 256) * 4
+    assert L.vidar_gemm_workspace_bytes(256, 256, 184950, 1, 1, 1) == s * 256 * 256 * 4          # the product alone
+    assert L.vidar_gemm_workspace_bytes(256, 256, 184950, 1, 1, 2) == s * (256 * 256 + 256) * 4  # ... with A's row sums
     assert L.vidar_gemm_splits(256, 256, 184950, 1, 1, 0) == 1 and L.vidar_gemm_workspace_bytes(256, 256, 64, 1, 0, 0) == 0
     # a single-slab reduced product still answers for one slab + one row: the row sums force the slab path
     assert L.vidar_gemm_splits(128, 128, 32, 1, 1, 1) == 1
-    assert L.vidar_gemm_workspace_bytes(128, 128, 32, 1, 1, 1) == (128 * 128 + 128) * 4
+    # a single slab is written straight to C: no scratch unless the row sums ride along
+    assert L.vidar_gemm_workspace_bytes(128, 128, 32, 1, 1, 1) == 0
+    assert L.vidar_gemm_workspace_bytes(128, 128, 32, 1, 1, 2) == (128 * 128 + 128) * 4

@@ -465,9 +465,9 @@ int vidar_dvxlr2_render_f32(const float* sigma, const float* origin, const float
                              (hipStream_t)stream);
 }
 
-size_t vidar_dvxlr_get_grad_sigma_workspace_bytes(int N, int T, int Z, int Y, int X) {
-  if (bad_dims(N, 0, T, Z, Y, X)) return 0;
-  return sizeof(float) * (size_t)N * T * Z * Y * X * kScatterCopies * 2;   // _v2: two volumes; v1 uses half
+size_t vidar_dvxlr_get_grad_sigma_workspace_bytes(int N, int T, int Z, int Y, int X, int volumes) {
+  if (bad_dims(N, 0, T, Z, Y, X) || volumes < 1 || volumes > 2) return 0;
+  return sizeof(float) * (size_t)N * T * Z * Y * X * kScatterCopies * volumes;   // 1: get_grad_sigma, 2: _v2 (two volumes)
 }
 
 int vidar_dvxlr_get_grad_sigma_f32(const float* elementwise_mult, const float* indices,
@@ -501,7 +501,7 @@ int vidar_dvxlr2_get_grad_sigma_f32(const float* elementwise_mult, const float* 
   VIDAR_ENTER();
   if (bad_dims(N, M, T, Z, Y, X) || L < 0) return VIDAR_ERR_BAD_ARG;
   const size_t n = (size_t)N * T * Z * Y * X;
-  const bool copies = workspace != nullptr && workspace_bytes >= vidar_dvxlr_get_grad_sigma_workspace_bytes(N, T, Z, Y, X);
+  const bool copies = workspace != nullptr && workspace_bytes >= vidar_dvxlr_get_grad_sigma_workspace_bytes(N, T, Z, Y, X, 2);
   float* acc = copies ? (float*)workspace : grad_sigma;
   float* acc2 = copies ? (float*)workspace + n * kScatterCopies : grad_sigma_regul;
   hipStream_t s_ = (hipStream_t)stream;

@@ -307,7 +307,11 @@ __device__ __forceinline__ void fetch(Staged<PREC>& sa, Staged<PREC>& sb, const 
 
 // the k loop of one tile.  On entry the staging registers hold (or are about to receive) the tile's first k-step.
 // sum over the staged k of a thread's A values, per row of its row quad (MN-major staging: every float4 of a thread is
-// the same four consecutive rows at another k; rows / k outside the matrix were read as 0)
+// the same four consecutive rows at another k).  k past the operand's END reads 0 (the descriptor's range check), but a
+// float4 that straddles m >= M inside the operand does NOT: with lda == M it reads the first elements of the NEXT k-row,
+// so the components of rows >= M hold garbage (possibly Inf / NaN).  Every row is its own vector component and the
+// store's `cur.m0 + tid < g.M` guard drops those components: that guard is load-bearing
+// (tests/test_gemm_gpu.py::test_rowsum_with_ragged_rows).  Buffer loads need dword alignment only (no 16-byte rule).
 template <int PREC>
 __device__ __forceinline__ void add_rowsum(f32x4& rs, const Staged<PREC>& sa) {
 #pragma unroll
@@ -755,9 +759,12 @@ int vidar_gemm_splits(int M, int N, int K, int batch, int precision, int reduce)
 size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision, int reduce) {
   if (!reduce) return 0;
   const int s = vidar_gemm_splits(M, N, K, batch, precision, reduce);
-  // Z slabs of [M, N] + Z partial rows of [M] (the optional row sums of A); a single-slab product without row sums
-  // needs none, but the query cannot know about the row sums: it always answers for them
-  return (size_t)batch * s * ((size_t)M * N + M) * sizeof(float);
+  // reduce == 1: the product alone -- Z = batch * splits slabs of [M, N], none when there is a single slab (it is
+  // written straight to C);  reduce == 2: the product WITH the row sums of A (a_rowsum) -- the slabs plus Z partial
+  // rows of [M], also for a single slab
+  const size_t Z = (size_t)batch * s;
+  if (reduce == 1) return Z > 1 ? Z * (size_t)M * N * sizeof(float) : 0;
+  return Z * ((size_t)M * N + M) * sizeof(float);
 }
 
 int vidar_gemm_f32(const float* A, int64_t lda, int a_layout, const float* B, int64_t ldb, int b_layout, float* C,

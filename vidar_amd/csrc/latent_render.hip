@@ -320,9 +320,9 @@ inline dim3 lr_grid(int bs, int Q) { return dim3((Q + kCellsPerBlock - 1) / kCel
 
 extern "C" {
 
-size_t vidar_latent_render_bwd_workspace_bytes(int bs, int H, int W, int Z) {
-  if (bs <= 0 || H <= 0 || W <= 0 || Z <= 0) return 0;
-  return sizeof(float) * 2 * (size_t)bs * H * W * Z * kCopies;     // gather_bwd: two maps; prob_bwd uses half
+size_t vidar_latent_render_bwd_workspace_bytes(int bs, int H, int W, int Z, int maps) {
+  if (bs <= 0 || H <= 0 || W <= 0 || Z <= 0 || maps < 1 || maps > 2) return 0;
+  return sizeof(float) * (size_t)maps * bs * H * W * Z * kCopies;   // maps: 1 = prob_bwd (grad_occ), 2 = gather_bwd
 }
 
 int vidar_latent_render_prob_fwd_f32(const float* occ, float* path_prob, int bs, int H, int W, int Z,
@@ -381,7 +381,7 @@ int vidar_latent_render_gather_bwd_f32(const float* path_prob, const float* lora
   hipStream_t s = (hipStream_t)stream;
   Geo g{H, W, grid_num, step, 0, eps};
   const size_t n = (size_t)bs * H * W * Z;
-  const bool copies = workspace != nullptr && workspace_bytes >= vidar_latent_render_bwd_workspace_bytes(bs, H, W, Z) &&
+  const bool copies = workspace != nullptr && workspace_bytes >= vidar_latent_render_bwd_workspace_bytes(bs, H, W, Z, 2) &&
                       (((uintptr_t)workspace | (uintptr_t)grad_path_prob | (uintptr_t)grad_lora_a) & 15u) == 0;
   float* sp = copies ? (float*)workspace : grad_path_prob;
   float* sa = copies ? (float*)workspace + n * kCopies : grad_lora_a;

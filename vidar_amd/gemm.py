@@ -114,7 +114,7 @@ def gemm_raw(A, lda, a_layout, B, ldb, b_layout, C, ldc, M, N, K, *, batch=1, sA
     if reduce:
         f = L.vidar_gemm_workspace_bytes
         f.restype = ctypes.c_size_t
-        nbytes = int(f(int(M), int(N), int(K), int(batch), int(precision), 1))
+        nbytes = int(f(int(M), int(N), int(K), int(batch), int(precision), 2 if a_rowsum is not None else 1))
         if nbytes:
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=C.device)
     flops = 2.0 * M * N * K * batch

@@ -47,7 +47,7 @@ class _PathProb(Function):
         grid_num, step, act = ctx.cfg
         bs, H, W, Z = occ.shape
         g = torch.empty_like(occ)
-        ws, wsp, wsn = workspace(lib().vidar_latent_render_bwd_workspace_bytes, bs, H, W, Z, like=occ)
+        ws, wsp, wsn = workspace(lib().vidar_latent_render_bwd_workspace_bytes, bs, H, W, Z, 1, like=occ)
         with TIMER.span("lr_prob_bwd", 4 * occ.numel() * 3):
           check(lib().vidar_latent_render_prob_bwd_f32(ptr(occ), ptr(grad_prob.float().contiguous()),
                                                      ptr(g), bs, H, W, Z, grid_num,
@@ -79,7 +79,7 @@ class _RayGather(Function):
         grid_num, step, eps = ctx.cfg
         bs, H, W, Z = prob.shape
         gp = torch.empty_like(prob); ga = torch.empty_like(a)
-        ws, wsp, wsn = workspace(lib().vidar_latent_render_bwd_workspace_bytes, bs, H, W, Z, like=prob)
+        ws, wsp, wsn = workspace(lib().vidar_latent_render_bwd_workspace_bytes, bs, H, W, Z, 2, like=prob)
         with TIMER.span("lr_gather_bwd", 4 * prob.numel() * 7):
           check(lib().vidar_latent_render_gather_bwd_f32(ptr(prob), ptr(a), ptr(feat), ptr(msum),
                                                        ptr(grad_feat.float().contiguous()), ptr(gp),

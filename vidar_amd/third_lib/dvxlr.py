@@ -32,7 +32,7 @@ def get_grad_sigma(elementwise_mult, indices, tindex, sigma_shape):
     N, T, Z, Y, X = sigma_shape.shape
     M, L = elementwise_mult.shape[1], elementwise_mult.shape[2]
     grad = torch.empty((N, T, Z, Y, X), device=elementwise_mult.device)
-    ws, wsp, wsn = workspace(lib().vidar_dvxlr_get_grad_sigma_workspace_bytes, N, T, Z, Y, X, like=grad)
+    ws, wsp, wsn = workspace(lib().vidar_dvxlr_get_grad_sigma_workspace_bytes, N, T, Z, Y, X, 1, like=grad)
     check(lib().vidar_dvxlr_get_grad_sigma_f32(ptr(elementwise_mult), ptr(indices), ptr(tindex),
                                                ptr(grad), N, M, L, T, Z, Y, X, wsp, wsn,
                                                stream_of(grad)), "dvxlr.get_grad_sigma")

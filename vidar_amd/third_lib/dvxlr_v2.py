@@ -37,7 +37,7 @@ def get_grad_sigma_v2(elementwise_mult, indices, tindex, sigma_shape, indicator,
     M, L = elementwise_mult.shape[1], elementwise_mult.shape[2]
     dev = elementwise_mult.device
     g = torch.empty((N, T, Z, Y, X), device=dev); g2 = torch.empty((N, T, Z, Y, X), device=dev)
-    ws, wsp, wsn = workspace(lib().vidar_dvxlr_get_grad_sigma_workspace_bytes, N, T, Z, Y, X, like=g)
+    ws, wsp, wsn = workspace(lib().vidar_dvxlr_get_grad_sigma_workspace_bytes, N, T, Z, Y, X, 2, like=g)
     check(lib().vidar_dvxlr2_get_grad_sigma_f32(ptr(elementwise_mult), ptr(indices), ptr(tindex),
                                                 ptr(indicator), ptr(grad_ray_pred), ptr(g), ptr(g2),
                                                 N, M, L, T, Z, Y, X, wsp, wsn, stream_of(g)),
