@@ -437,6 +437,18 @@ def kernel_rooflines(dev):
         rows[-1]["serial_chain"] = dict(longest_ray_steps=longest, total_steps=cnt,
                                         us_per_step_of_longest_ray=round(rows[-1]["avg_ms"] * 1e3 / max(longest, 1), 3),
                                         waves=(N * M + 63) // 64, simds=1024)
+        # ... and as a MEASUREMENT: the same entry point on the longest ray ALONE is the launch's critical path (nothing
+        # can finish before its slowest ray has); launch time / that = how far the 30 000-ray launch is from the
+        # latency floor of its own traversal -- the figure this kernel is held to instead of an HBM fraction
+        j = int(live.sum(-1).reshape(-1).argmax())
+        n_, m_ = divmod(j, M)
+        p1, t1 = points[n_:n_ + 1, m_:m_ + 1].contiguous(), tindex[n_:n_ + 1, m_:m_ + 1].contiguous()
+        s1, o1 = sigma[n_:n_ + 1].contiguous(), origin[n_:n_ + 1].contiguous()
+        one = hip_time(lambda: dvr.render_forward(s1, o1, p1, t1, [T_, 16, 200, 200], "train"), iters=20)
+        rows[-1]["latency_model"] = dict(
+            longest_ray_alone_ms=round(one, 4), launch_over_longest_ray=round(rows[-1]["avg_ms"] / one, 2),
+            note="a launch cannot beat its longest ray: `longest_ray_alone_ms` (one ray, same entry point, includes the "
+                 "launch overhead of ~5 us) is the floor; the HBM fraction of this row is reported for completeness only")
         add(f"dvr.render[M={M}]", hip_time(lambda: dvr.render(sigma, origin, points, tindex, "l1")),
             2 * vol + N * M * 24 + cnt * 12,
             bound="step-parallel traversal, lane-per-step fp32 atomics (coalesced along a ray), not HBM")

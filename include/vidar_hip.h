@@ -197,16 +197,20 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
  * fwd writes out [bs*Qn,Nq,H*C] and the prepared operands loc_out [bs*Qn,Nq,H,L,P,2] / w_out [bs*Qn,Nq,H,L,P]
  * (what the backward needs); bwd takes those and writes grad_value (zeroed + accumulated),
  * grad_off_raw, grad_logit_raw (fully written, raw layouts).  workspace as for vidar_msda_bwd_f32 with
- * B = bs*Qn. */
+ * B = bs*Qn.
+ * merge_queue = 1: the op also takes the MEAN over the Qn queue entries that TemporalSelfAttention applies to its output
+ * (`output.view(bs, Qn, Nq, C).mean(1)`, temporal_self_attention.py:256-264): out / grad_out are [bs,Nq,H*C], the Qn
+ * entries of a (batch, query, head) are gathered by one item and summed in registers (Qn*L*P <= 64); loc_out / w_out and
+ * the gradients keep the layouts above.  merge_queue = 0: out / grad_out [bs*Qn,Nq,H*C]. */
 int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
                              const int64_t* level_start_index, const float* off_raw, const float* logit_raw,
                              const float* ref, float* loc_out, float* w_out, float* out, int bs, int Qn, int Nv,
-                             int H, int C, int Nq, int L, int P, int R, int mode, void* stream);
+                             int H, int C, int Nq, int L, int P, int R, int mode, int merge_queue, void* stream);
 int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
                              const int64_t* level_start_index, const float* sampling_loc,
                              const float* attn_weight, const float* grad_out, float* grad_value,
                              float* grad_off_raw, float* grad_logit_raw, int bs, int Qn, int Nv, int H, int C,
-                             int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream);
+                             int Nq, int L, int P, int merge_queue, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * y = LayerNorm(dropout(x) + residual) and its backward in one pass each (csrc/norm_fuse.hip): the tail of every

@@ -124,6 +124,23 @@ struct Prep {
   float* g_off_raw;          // backward outputs
   float* g_logit_raw;
   int Qn, R, mode;
+  // merge != 0 (fused forward only): the Qn queue entries of a (batch, query, head) are ONE item whose Qn * L * P samples
+  // read Qn different `value` planes, and the kernel stores their MEAN -- TemporalSelfAttention's
+  // `output.view(bs, Qn, Nq, C).mean(1)` (temporal_self_attention.py:256-264) without the [bs*Qn, Nq, C] round trip.
+  // Items then count (b, q, h) of the bs batch rows; the saved loc / w keep their [bs*Qn, ...] layout for the backward.
+  int merge;
+};
+
+// merged queue entries in the backward: grad_out is [bs, Nq, H*C], item' = ((b*Qn + qn)*Nq + q)*H + h reads the line of
+// (b, q, h), scaled by 1/Qn
+struct GoMap {
+  int Qn, NqH;
+  float scale;
+  __device__ __forceinline__ int64_t at(int64_t item) const {
+    if (Qn <= 1) return item;
+    const int64_t bp = item / NqH;
+    return item - (bp - bp / Qn) * NqH;
+  }
 };
 
 // index of (item, lp) inside the raw [bs, Nq, H, Qn, LP] layout
@@ -185,30 +202,38 @@ __device__ __forceinline__ void stage_records(const Prep& pr, const float* __res
     __syncthreads();
     return;
   }
+  // merged queue entries: an item carries Qm = Qn groups of LPg = L*P samples (LP == Qn * L * P there); group g of item
+  // (b, q, h) is queue entry g: batch row b*Qn + g of ref / value / the saved operands, and the raw layout
+  // [bs, Nq, H, Qn, L*P] makes the item's Qn * L*P raw values contiguous
+  const int Qm = pr.merge ? pr.Qn : 1, LPg = LP / Qm;
   for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
     const int it = i / LP, lp = i - it * LP;
     const int64_t item = im.at(it);
-    const int64_t raw = raw_index(item, lp, H, Nq, LP, pr.Qn);
-    const int l = lp / P, p = lp - l * P;
+    const int g = lp / LPg, lpg = lp - g * LPg;
+    const int64_t raw = pr.merge ? item * LP + lp : raw_index(item, lp, H, Nq, LP, pr.Qn);
+    const int l = lpg / P, p = lpg - l * P;
     const int rr = pr.mode == 0 ? l : p % pr.R;
     const float2 o = reinterpret_cast<const float2*>(pr.off_raw)[raw];
-    const float2 rf = reinterpret_cast<const float2*>(pr.ref)[(item / H) * pr.R + rr];
+    const int64_t bq = item / H;                     // merge: (b, q) of the bs rows -> row b*Qn + g of ref
+    const int64_t refrow = pr.merge ? ((bq / Nq) * Qm + g) * Nq + bq % Nq : bq;
+    const float2 rf = reinterpret_cast<const float2*>(pr.ref)[refrow * pr.R + rr];
     float* r = rec + rec_at(it, lp, LP);
     r[0] = rf.x + o.x / (float)lv.Wl[l];
     r[1] = rf.y + o.y / (float)lv.Hl[l];
     r[2] = pr.logit_raw[raw];
   }
   __syncthreads();
-  // softmax over the LP logits of every item: 8 lanes per item, values in registers (LP <= 64)
+  // softmax over the LPg logits of every (item, group): 8 lanes per unit, values in registers (LPg <= 64)
   const int nlan = 8;
-  for (int it = threadIdx.x / nlan; it < nvalid; it += kThr / nlan) {
+  for (int u = threadIdx.x / nlan; u < nvalid * Qm; u += kThr / nlan) {
+    const int it = u / Qm, lp0 = (u - it * Qm) * LPg;
     const int sub = threadIdx.x % nlan;
     float e[kMaxLP / 8];
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < kMaxLP / 8; ++k) {
       const int lp = sub + k * nlan;
-      e[k] = lp < LP ? rec[rec_at(it, lp, LP) + 2] : -INFINITY;
+      e[k] = lp < LPg ? rec[rec_at(it, lp0 + lp, LP) + 2] : -INFINITY;
       m = fmaxf(m, e[k]);
     }
 #pragma unroll
@@ -217,7 +242,7 @@ __device__ __forceinline__ void stage_records(const Prep& pr, const float* __res
 #pragma unroll
     for (int k = 0; k < kMaxLP / 8; ++k) {
       const int lp = sub + k * nlan;
-      e[k] = lp < LP ? expf(e[k] - m) : 0.f;
+      e[k] = lp < LPg ? expf(e[k] - m) : 0.f;
       sum += e[k];
     }
 #pragma unroll
@@ -225,7 +250,7 @@ __device__ __forceinline__ void stage_records(const Prep& pr, const float* __res
 #pragma unroll
     for (int k = 0; k < kMaxLP / 8; ++k) {
       const int lp = sub + k * nlan;
-      if (lp < LP) rec[rec_at(it, lp, LP) + 2] = e[k] / sum;
+      if (lp < LPg) rec[rec_at(it, lp0 + lp, LP) + 2] = e[k] / sum;
     }
   }
   __syncthreads();
@@ -233,7 +258,12 @@ __device__ __forceinline__ void stage_records(const Prep& pr, const float* __res
     for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
       const int it = i / LP, lp = i - it * LP;
       const float* r = rec + rec_at(it, lp, LP);
-      const int64_t e = im.at(it) * LP + lp;
+      int64_t e = im.at(it) * LP + lp;
+      if (pr.merge) {                                  // saved operands stay [bs*Qn, Nq, H, L*P]
+        const int64_t item = im.at(it), bq = item / H;
+        const int g = lp / LPg;
+        e = ((((bq / Nq) * Qm + g) * Nq + bq % Nq) * H + item % H) * LPg + (lp - g * LPg);
+      }
       reinterpret_cast<float2*>(pr.loc_out)[e] = make_float2(r[0], r[1]);
       pr.w_out[e] = r[2];
     }
@@ -243,15 +273,17 @@ __device__ __forceinline__ void stage_records(const Prep& pr, const float* __res
 // corner arithmetic of one sample, once: (x, y, w) in the record -> the forward or backward record
 template <int kThr, bool BWD>
 __device__ __forceinline__ void corner_records(const GLevels& lv, float* rec, const ItemMap& im, int Nv,
-                                               int H, int Nq, int L, int P) {
-  const int LP = L * P;
+                                               int H, int Nq, int L, int P, int Qm = 1) {
+  // Qm > 1 (merged queue entries, forward): LP = Qm * L * P samples per item, group g reads value plane b*Qm + g
+  const int LP = Qm * L * P, LPg = L * P;
   const int nvalid = im.nvalid;
   for (int i = threadIdx.x; i < nvalid * LP; i += kThr) {
     const int it = i / LP, lp = i - it * LP;
-    const int l = lp / P;
+    const int g = lp / LPg;
+    const int l = (lp - g * LPg) / P;
     const int64_t item = im.at(it);
     const int h = (int)(item % H);
-    const int b = (int)(item / H / Nq);
+    const int b = (int)(item / H / Nq) * Qm + g;
     const int Hl = lv.Hl[l], Wl = lv.Wl[l];
     float* r = rec + rec_at(it, lp, LP);
     const float x = pix(r[0], Wl), y = pix(r[1], Hl), w = r[2];
@@ -289,14 +321,15 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
     Prep pr) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ GLevels lv;
-  const int LP = L * P;
+  const int Qm = pr.merge ? pr.Qn : 1;
+  const int LP = Qm * L * P;                  // samples per item (merged queue entries: Qn groups of L * P)
   ItemMap im;
   if (!item_map(im, blockIdx.x, nblocks, n_items, H, head_major)) return;
   load_levels(lv, shapes, lsi, L);
   __syncthreads();
   const int nvalid = im.nvalid;
-  stage_records<kThreads>(pr, loc, attw, lv, smem, im, H, Nq, L, P);
-  corner_records<kThreads, false>(lv, smem, im, Nv, H, Nq, L, P);
+  stage_records<kThreads>(pr, loc, attw, lv, smem, im, H, Nq, Qm * L, P);
+  corner_records<kThreads, false>(lv, smem, im, Nv, H, Nq, L, P, Qm);
   const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
   if (it >= nvalid) return;
   const unsigned sub16 = sub * 16;
@@ -313,6 +346,7 @@ __global__ __launch_bounds__(kThreads) void msda_fwd_kernel(
     acc.z += w.x * v00.z + w.y * v01.z + w.z * v10.z + w.w * v11.z;
     acc.w += w.x * v00.w + w.y * v01.w + w.z * v10.w + w.w * v11.w;
   }
+  if (Qm > 1) { const float s = 1.f / Qm; acc.x *= s; acc.y *= s; acc.z *= s; acc.w *= s; }
   *reinterpret_cast<float4*>(out + im.at(it) * kCh + sub * 4) = acc;
 }
 
@@ -369,7 +403,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ grad_out, float* __restrict__ grad_value,
     float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv, int H, int Nq, int L, int P,
-    int64_t n_items, int nblocks, Prep pr) {
+    int64_t n_items, int nblocks, Prep pr, GoMap gm) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int LP = L * P;
   float* s_loc = smem;                         // [kBItems][LP*2]  in: loc, out: grad_loc
@@ -392,7 +426,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_kernel(
     const int64_t voff = (int64_t)b * Nv * row_stride + h * kCh + ch;
     const float* vb = value + voff;
     float* gvb = grad_value + voff;
-    const float go = grad_out[item * kCh + ch];
+    const float go = grad_out[gm.at(item) * kCh + ch] * gm.scale;
     float* ml = s_loc + it * LP * 2;
     float* mw = s_w + it * LP;
     for (int l = 0; l < L; ++l) {
@@ -673,7 +707,7 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
     const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
-    int H, int L, int P, int go_bytes) {
+    int H, int L, int P, int go_bytes, GoMap gm) {
   __shared__ __attribute__((aligned(16))) float s_win[kTWaves][kWinLines * kCh];
   __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, bottom-left, top-right, bottom-right}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -695,7 +729,7 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const bool valid = base + lane < n;
     const int s = rec[s0 + (valid ? base + lane : 0)];
     const float2 xy = reinterpret_cast<const float2*>(loc)[s];
-    const float aw = valid ? attw[s] : 0.f;
+    const float aw = valid ? attw[s] * gm.scale : 0.f;   // (merged queue entries: grad_out / Qn rides on the weight)
     const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
     const int h0 = (int)floorf(y), w0 = (int)floorf(x);
     const float lh = y - h0, lw = x - w0;
@@ -704,7 +738,7 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     s_par[wave][lane] = make_float4(hh * (1.f - lw), lha * (1.f - lw), hh * lw, lha * lw);
     const int line = min(max(h0 + 1 - ty * kTile, 0), kTile - 1) * kWin + min(max(w0 + 1 - tx * kTile, 0), kTile - 1);
     // one word per sample for the v_readlane hand-off: byte offset of its grad_out line (a multiple of 128) | window line
-    const int pack = ((s / LP) * (kCh * 4)) | line;
+    const int pack = ((int)gm.at(s / LP) * (kCh * 4)) | line;
     __builtin_amdgcn_wave_barrier();
     // groups of 8 samples, software-pipelined by hand: the weight pairs and grad_out lines of group k+1 are
     // requested before the window updates of group k (samples past the end of the chunk carry zero weights)
@@ -787,7 +821,7 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
     const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ grad_out, float* __restrict__ grad_loc, float* __restrict__ grad_w, int Nv,
-    int H, int Nq, int L, int P, int64_t n_items, int nblocks, int head_major, Prep pr) {
+    int H, int Nq, int L, int P, int64_t n_items, int nblocks, int head_major, Prep pr, GoMap gm) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ GLevels lv;
   __shared__ float s_dot[kItems];
@@ -802,7 +836,8 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
   const int it = threadIdx.x / kLanes, sub = threadIdx.x % kLanes;
   if (it < nvalid) {
     const unsigned sub16 = sub * 16;
-    const float4 go = *reinterpret_cast<const float4*>(grad_out + im.at(it) * kCh + sub * 4);
+    float4 go = *reinterpret_cast<const float4*>(grad_out + gm.at(im.at(it)) * kCh + sub * 4);
+    go.x *= gm.scale; go.y *= gm.scale; go.z *= gm.scale; go.w *= gm.scale;
     float* r = smem + rec_at(it, 0, LP);
     // (the DPP reductions are convergent operations, which keeps the compiler from unrolling a loop with a
     //  run-time trip count: unrolled by hand, 16 lines in flight per wave)
@@ -927,11 +962,13 @@ static int msda_fwd_launch(const float* value, const int64_t* spatial_shapes,
                            const float* attn_weight, float* out, int B, int Nv, int H, int C, int Nq, int L,
                            int P, const Prep& pr, void* stream) {
   if (msda_bad(B, Nv, H, C, Nq, L, P)) return VIDAR_ERR_BAD_ARG;
-  const int64_t n_items = (int64_t)B * Nq * H;
+  const int Qm = pr.merge ? pr.Qn : 1;         // merged queue entries: B = bs * Qn value planes, bs * Nq * H items
+  if (Qm * L * P > kMaxLP || B % Qm != 0) return VIDAR_ERR_BAD_ARG;
+  const int64_t n_items = (int64_t)(B / Qm) * Nq * H;
   if (n_items == 0) return 0;
   int nblocks, grid;
   gather_grid(n_items, H, nblocks, grid);
-  const size_t lds = rec_lds_bytes(L * P);
+  const size_t lds = rec_lds_bytes(Qm * L * P);
   if (!allow_lds(msda_fwd_kernel, lds)) { (void)hipGetLastError(); return VIDAR_ERR_BAD_ARG; }
   hipLaunchKernelGGL(msda_fwd_kernel, dim3(grid), dim3(kThreads), lds, (hipStream_t)stream, value,
                      spatial_shapes, level_start_index, sampling_loc, attn_weight, out, Nv, H, Nq, L,
@@ -946,6 +983,8 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
                            int Nq, int L, int P, void* workspace, size_t workspace_bytes, const Prep& pr,
                            void* stream) {
   if (msda_bad(B, Nv, H, C, Nq, L, P)) return VIDAR_ERR_BAD_ARG;
+  // merged queue entries (pr.merge): grad_out is [B / Qn, Nq, H*C] and every queue entry reads its (b, q, h) line / Qn
+  const GoMap gm{pr.merge ? pr.Qn : 1, Nq * H, pr.merge ? 1.f / pr.Qn : 1.f};
   hipStream_t s = (hipStream_t)stream;
   const size_t vbytes = sizeof(float) * (size_t)B * Nv * H * C;
   if (vbytes) {
@@ -979,14 +1018,14 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
-                       Nv, H, L, P, (int)(n_items * kCh * 4));
+                       Nv, H, L, P, (int)(n_items / gm.Qn * kCh * 4), gm);
     int nblocks, grid;
     gather_grid(n_items, H, nblocks, grid);
     const size_t lds = rec_lds_bytes(L * P);
     if (!allow_lds(msda_bwd_locw_kernel, lds)) { (void)hipGetLastError(); return VIDAR_ERR_BAD_ARG; }
     hipLaunchKernelGGL(msda_bwd_locw_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_out, grad_sampling_loc,
-                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, g_head_major, pr);
+                       grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, g_head_major, pr, gm);
     return vidar_last_error();
   }
   const int nblocks = (int)((n_items + kBItems - 1) / kBItems);
@@ -994,7 +1033,7 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
   const size_t lds = sizeof(float) * (kBItems * L * P * 3 + kBItems);
   hipLaunchKernelGGL(msda_bwd_kernel, dim3(grid), dim3(kThreads), lds, s, value, spatial_shapes,
                      level_start_index, sampling_loc, attn_weight, grad_out, grad_value,
-                     grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr);
+                     grad_sampling_loc, grad_attn_weight, Nv, H, Nq, L, P, n_items, nblocks, pr, gm);
   return vidar_last_error();
 }
 
@@ -1063,9 +1102,9 @@ int vidar_msda_bwd_f32(const float* value, const int64_t* spatial_shapes,
 int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
                              const int64_t* level_start_index, const float* off_raw, const float* logit_raw,
                              const float* ref, float* loc_out, float* w_out, float* out, int bs, int Qn, int Nv,
-                             int H, int C, int Nq, int L, int P, int R, int mode, void* stream) {
+                             int H, int C, int Nq, int L, int P, int R, int mode, int merge_queue, void* stream) {
   VIDAR_ENTER();
-  if (prep_bad(bs, Qn, R, mode, L, P)) return VIDAR_ERR_BAD_ARG;
+  if (prep_bad(bs, Qn, R, mode, L, P) || (merge_queue != 0 && merge_queue != 1)) return VIDAR_ERR_BAD_ARG;
   if ((int64_t)bs * Qn * Nq * H == 0) return msda_bad(bs * Qn, Nv, H, C, Nq, L, P) ? VIDAR_ERR_BAD_ARG : 0;
   if (!off_raw || !logit_raw || !ref || !loc_out || !w_out) return VIDAR_ERR_BAD_ARG;   // (empty tensors are NULL)
   const int cb = batch_per_launch(bs * Qn, Nv, H) / Qn;            // whole batch items (Qn queue entries each) per launch
@@ -1078,8 +1117,9 @@ int vidar_msda_fused_fwd_f32(const float* value, const int64_t* spatial_shapes,
     Prep pr{};
     pr.off_raw = off_raw + q0 * is * LP * 2; pr.logit_raw = logit_raw + q0 * is * LP; pr.ref = ref + q0 * Nq * R * 2;
     pr.loc_out = loc_out + q0 * is * LP * 2; pr.w_out = w_out + q0 * is * LP;
-    pr.Qn = Qn; pr.R = R; pr.mode = mode;
-    const int rc = msda_fwd_launch(value + q0 * vs, spatial_shapes, level_start_index, nullptr, nullptr, out + q0 * is * kCh,
+    pr.Qn = Qn; pr.R = R; pr.mode = mode; pr.merge = merge_queue;
+    float* out_b = out + (merge_queue ? (int64_t)b0 : q0) * is * kCh;          // merged: one output row block per batch row
+    const int rc = msda_fwd_launch(value + q0 * vs, spatial_shapes, level_start_index, nullptr, nullptr, out_b,
                                    nb * Qn, Nv, H, C, Nq, L, P, pr, stream);
     if (rc != 0) return rc;
     b0 += nb;
@@ -1091,9 +1131,9 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
                              const int64_t* level_start_index, const float* sampling_loc,
                              const float* attn_weight, const float* grad_out, float* grad_value,
                              float* grad_off_raw, float* grad_logit_raw, int bs, int Qn, int Nv, int H, int C,
-                             int Nq, int L, int P, void* workspace, size_t workspace_bytes, void* stream) {
+                             int Nq, int L, int P, int merge_queue, void* workspace, size_t workspace_bytes, void* stream) {
   VIDAR_ENTER();
-  if (bs < 0 || Qn <= 0) return VIDAR_ERR_BAD_ARG;
+  if (bs < 0 || Qn <= 0 || (merge_queue != 0 && merge_queue != 1)) return VIDAR_ERR_BAD_ARG;
   if ((int64_t)bs * Qn * Nq * H != 0 && (!grad_off_raw || !grad_logit_raw)) return VIDAR_ERR_BAD_ARG;
   if (bs == 0) return msda_bwd_launch(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_out,
                                       grad_value, nullptr, nullptr, 0, Nv, H, C, Nq, L, P, workspace, workspace_bytes,
@@ -1107,8 +1147,10 @@ int vidar_msda_fused_bwd_f32(const float* value, const int64_t* spatial_shapes,
     const int64_t q0 = (int64_t)b0 * Qn;
     Prep pr{};
     pr.g_off_raw = grad_off_raw + q0 * is * LP * 2; pr.g_logit_raw = grad_logit_raw + q0 * is * LP; pr.Qn = Qn;
+    pr.merge = merge_queue;
     const int rc = msda_bwd_launch(value + q0 * vs, spatial_shapes, level_start_index, sampling_loc + q0 * is * LP * 2,
-                                   attn_weight + q0 * is * LP, grad_out + q0 * is * kCh, grad_value + q0 * vs, nullptr,
+                                   attn_weight + q0 * is * LP, grad_out + (merge_queue ? (int64_t)b0 : q0) * is * kCh,
+                                   grad_value + q0 * vs, nullptr,
                                    nullptr, nb * Qn, Nv, H, C, Nq, L, P, workspace, workspace_bytes, pr, stream);
     if (rc != 0) return rc;
     b0 += nb;

@@ -142,10 +142,12 @@ def compose_operands(off_raw, logit_raw, ref, shapes, H, Qn, L, P, mode):
 
 
 class FusedDeformAttnFunction(Function):
-    """apply(value [bs*Qn,Nv,H,C], shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode) -> [bs*Qn, Nq, H*C]"""
+    """apply(value [bs*Qn,Nv,H,C], shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode, merge_queue=False)
+    -> [bs*Qn, Nq, H*C], or with merge_queue the mean over the Qn queue entries [bs, Nq, H*C] (TemporalSelfAttention's
+    `output.view(bs, Qn, Nq, C).mean(1)` inside the gather)"""
 
     @staticmethod
-    def forward(ctx, value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode):
+    def forward(ctx, value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode, merge_queue=False):
         ctx.in_dtypes = (value.dtype, off_raw.dtype, logit_raw.dtype)
         f = lambda t: t.float().contiguous()
         i = lambda t: t.to(device=value.device, dtype=torch.int64).contiguous()
@@ -158,13 +160,14 @@ class FusedDeformAttnFunction(Function):
             raise RuntimeError("inconsistent fused MSDA operand shapes")
         loc = torch.empty((Bq, Nq, H, L, P, 2), dtype=torch.float32, device=value.device)
         w = torch.empty((Bq, Nq, H, L, P), dtype=torch.float32, device=value.device)
-        out = torch.empty((Bq, Nq, H * C), dtype=torch.float32, device=value.device)
+        merge = bool(merge_queue) and Qn > 1
+        out = torch.empty((bs if merge else Bq, Nq, H * C), dtype=torch.float32, device=value.device)
         with TIMER.span(f"msda_fwd[L={L},P={P}]", msda_fwd_bytes(Bq, Nv, H, C, Nq, L, P)):
             check(lib().vidar_msda_fused_fwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(off_raw), ptr(logit_raw),
                                                  ptr(ref), ptr(loc), ptr(w), ptr(out), bs, Qn, Nv, H, C, Nq, L, P,
-                                                 R, mode, stream_of(value)), "ms_deform_attn_forward (fused)")
+                                                 R, mode, int(merge), stream_of(value)), "ms_deform_attn_forward (fused)")
         ctx.save_for_backward(value, shapes, lsi, loc, w)
-        ctx.cfg = (bs, Qn, L, P, off_raw.shape, logit_raw.shape)
+        ctx.cfg = (bs, Qn, L, P, off_raw.shape, logit_raw.shape, merge)
         return out
 
     @staticmethod
@@ -172,7 +175,7 @@ class FusedDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         import ctypes
         value, shapes, lsi, loc, w = ctx.saved_tensors
-        bs, Qn, L, P, off_shape, logit_shape = ctx.cfg
+        bs, Qn, L, P, off_shape, logit_shape, merge = ctx.cfg
         Bq, Nv, H, C = value.shape
         Nq = loc.shape[1]
         go = grad_output.float().contiguous()
@@ -183,17 +186,21 @@ class FusedDeformAttnFunction(Function):
         with TIMER.span(f"msda_bwd[L={L},P={P}]", msda_bwd_bytes(Bq, Nv, H, C, Nq, L, P)):
             check(lib().vidar_msda_fused_bwd_f32(ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(w), ptr(go),
                                                  ptr(gv), ptr(g_off), ptr(g_logit), bs, Qn, Nv, H, C, Nq, L, P,
-                                                 ptr(ws), ctypes.c_size_t(nbytes), stream_of(value)),
+                                                 int(merge), ptr(ws), ctypes.c_size_t(nbytes), stream_of(value)),
                   "ms_deform_attn_backward (fused)")
         dv, do, dl = ctx.in_dtypes
-        return gv.to(dv), None, None, g_off.to(do), g_logit.to(dl), None, None, None, None, None
+        return gv.to(dv), None, None, g_off.to(do), g_logit.to(dl), None, None, None, None, None, None
 
 
-def fused_deform_attn(value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode, im2col_step=64):
+def fused_deform_attn(value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode, im2col_step=64, merge_queue=False):
     """One entry for the three attention modules.  CUDA tensors: the fused HIP op.  Anything else (the
     oracle-routed CPU tests) or reference points that need a gradient: the reference's tensor program followed
-    by MultiScaleDeformableAttnFunction_fp32.apply (which has no CPU implementation of its own)."""
+    by MultiScaleDeformableAttnFunction_fp32.apply (which has no CPU implementation of its own).
+    merge_queue: also the mean over the Qn queue entries (TemporalSelfAttention) -> [bs, Nq, H*C]."""
     if value.is_cuda and not ref.requires_grad:
-        return FusedDeformAttnFunction.apply(value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode)
+        return FusedDeformAttnFunction.apply(value, shapes, lsi, off_raw, logit_raw, ref, Qn, L, P, mode, merge_queue)
     locations, weights = compose_operands(off_raw, logit_raw, ref, shapes, value.shape[2], Qn, L, P, mode)
-    return MultiScaleDeformableAttnFunction_fp32.apply(value, shapes, lsi, locations, weights, im2col_step)
+    out = MultiScaleDeformableAttnFunction_fp32.apply(value, shapes, lsi, locations, weights, im2col_step)
+    if merge_queue and Qn > 1:
+        out = out.view(out.shape[0] // Qn, Qn, out.shape[1], out.shape[2]).mean(1)
+    return out

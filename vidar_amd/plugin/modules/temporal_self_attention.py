@@ -73,8 +73,9 @@ class TemporalSelfAttention(nn.Module):
         logit_raw = self.attention_weights(query)
         if reference_points.shape[-1] == 2:
             # softmax / offset normalisation / reference add / queue permutes (:218-245) happen inside the op
+            # ... and so does the mean over the (prev, cur) pair (:256-264): the op returns [bs, Nq, C]
             out = fused_deform_attn(value, spatial_shapes, level_start_index, off_raw, logit_raw,
-                                    reference_points, Qn, L, P, 0, self.im2col_step)
+                                    reference_points, Qn, L, P, 0, self.im2col_step, merge_queue=True)
         elif reference_points.shape[-1] == 4:
             offsets = off_raw.view(bs, num_query, H, Qn, L, P, 2)
             weights = logit_raw.view(bs, num_query, H, Qn, L * P).softmax(-1)
@@ -85,11 +86,11 @@ class TemporalSelfAttention(nn.Module):
                 + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
             out = MultiScaleDeformableAttnFunction_fp32.apply(value, spatial_shapes, level_start_index,
                                                               locations, weights, self.im2col_step)
+            out = out.view(bs, Qn, num_query, embed_dims).mean(1)           # mean over the (prev, cur) pair
         else:
             raise ValueError("Last dim of reference_points must be 2 or 4, but get "
                              f"{reference_points.shape[-1]} instead.")
-        # mean over the (prev, cur) pair
-        out = out.view(bs, Qn, num_query, embed_dims).mean(1).to(identity.dtype)
+        out = out.to(identity.dtype)
         out = self.output_proj(out)
         if not self.batch_first:
             out = out.permute(1, 0, 2)
