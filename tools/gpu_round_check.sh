@@ -10,7 +10,7 @@ mkdir -p $out
 t0=$(date +%s)
 stamp() { echo "[$(( $(date +%s) - t0 )) s] $*"; }
 stamp "full GPU suite"
-timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -4 | tee $out/gpu_suite.log
+timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -12 | tee $out/gpu_suite.log
 stamp "smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $out/smoke.log
 stamp "bench (driver command), hard limit 480 s"
