@@ -201,15 +201,19 @@ def bench_dcn(which):
     from vidar_amd.plugin.backbones import dcn_col2im
     from vidar_amd._lib import lib, check, ptr, stream_of
     g = torch.Generator().manual_seed(0)
-    stds = [float(v) for v in os.environ.get("VIDAR_KBENCH_DCN_STD", "0,1.5").split(",")]
+    stds = [float(v) for v in os.environ.get("VIDAR_KBENCH_DCN_STD", "0,1.5,-1.5").split(",")]     # negative: SMOOTH offsets
     for N, C, H, W in ((6, 256, 58, 100), (24, 256, 58, 100), (6, 512, 29, 50)):
         x = torch.randn(N, C, H, W, generator=g).cuda()
         mask = torch.rand(N, 9, H, W, generator=g).cuda()
         gcols = torch.randn(N, C * 9, H * W, generator=g).cuda()
         cols = torch.empty_like(gcols)
         for std in stds:
-            off = (torch.randn(N, 18, H, W, generator=g) * std).cuda()
-            tag = f"N={N} C={C} {H}x{W} offsets~{std}px"
+            off = torch.randn(N, 18, H, W, generator=g)
+            if std < 0:       # spatially smooth like a convolution's output (the model's conv_offset): 7x7 box-filtered noise
+                off = torch.nn.functional.avg_pool2d(off, 7, stride=1, padding=3)
+                off = off / off.std()
+            off = (off * abs(std)).cuda()
+            tag = f"N={N} C={C} {H}x{W} offsets~{abs(std)}px" + (" smooth" if std < 0 else "")
             ms = timeit(lambda: check(lib().vidar_dcn_im2col_f32(ptr(x), ptr(off), ptr(mask), ptr(cols), N, C, H, W, H, W,
                                                                  3, 3, 1, 1, 1, stream_of(x)), "im2col"))
             report(f"dcn_im2col {tag}", ms, 4 * (x.numel() + cols.numel() + off.numel() + mask.numel()))
@@ -411,6 +415,9 @@ def bench_gemm_pmc(which):
 
 if __name__ == "__main__":
     import os
+    if os.environ.get("VIDAR_DCN_SORT_BINS") is not None:
+        from vidar_amd._lib import lib
+        lib().vidar_dcn_set_sort_bins(int(os.environ["VIDAR_DCN_SORT_BINS"]))
     if os.environ.get("VIDAR_MSDA_ITEM_ORDER") is not None:          # A/B of the gather kernels' item order (0 banded, 1 head-major)
         from vidar_amd._lib import lib
         lib().vidar_msda_set_item_order(int(os.environ["VIDAR_MSDA_ITEM_ORDER"]))
