@@ -415,9 +415,6 @@ def bench_gemm_pmc(which):
 
 if __name__ == "__main__":
     import os
-    if os.environ.get("VIDAR_DCN_SORT_BINS") is not None:
-        from vidar_amd._lib import lib
-        lib().vidar_dcn_set_sort_bins(int(os.environ["VIDAR_DCN_SORT_BINS"]))
     if os.environ.get("VIDAR_MSDA_ITEM_ORDER") is not None:          # A/B of the gather kernels' item order (0 banded, 1 head-major)
         from vidar_amd._lib import lib
         lib().vidar_msda_set_item_order(int(os.environ["VIDAR_MSDA_ITEM_ORDER"]))
