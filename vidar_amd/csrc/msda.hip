@@ -495,6 +495,11 @@ static_assert(kWinLines < 128, "the window line index shares a word with a 128-b
 constexpr int kChunk = VIDAR_MSDA_CHUNK;       // samples per chunk descriptor (tuning sweep: tools/tune_msda_tile.sh)
 constexpr int kMaxL = 16;                      // levels supported by the binned path
 constexpr int kTWaves = 4;                     // waves (= chunks, private 10 KB windows) per workgroup of the accumulate kernel
+#ifndef VIDAR_MSDA_TILE_GROUP
+#define VIDAR_MSDA_TILE_GROUP 8
+#endif
+constexpr int kGrp = VIDAR_MSDA_TILE_GROUP;    // samples per software-pipeline group of the accumulate kernel (grad_out lines in flight: 2 kGrp)
+static_assert(64 % kGrp == 0, "groups tile a 64-sample batch");
 // (16-byte sort records {x, y, attention weight, sample} that the accumulate kernel would read coalesced instead of
 //  gathering loc[s] / attw[s]: 1.24 vs 1.19 ms for the SCA backward -- the fill pass's scattered stores grow 4x; removed)
 
@@ -723,13 +728,31 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
   const int LP = L * P;
   const __amdgpu_buffer_rsrc_t go_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(grad_out), 0, go_bytes, 0x00020000);
   for (int i = lane; i < kWinLines * kCh / 4; i += 64) reinterpret_cast<float4*>(win)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // The per-sample operands come through two DEPENDENT gathers (record -> sample index -> location / weight): fetched at
+  // the top of a batch they leave the wave with nothing in flight for two memory latencies per 64 samples.  They are
+  // software-pipelined ACROSS batches instead: the sample indices are requested two batches ahead, locations / weights
+  // one batch ahead, under the current batch's window updates (round 6: SCA backward 1.206 -> 1.177 ms, coherent queries
+  // 1.336 -> 1.298 ms; twice / four times as many grad_out lines in flight per wave -- VIDAR_MSDA_TILE_GROUP 16 / 32 --
+  // measured 1.182 / 1.309 ms: latency is not what is left, profiles/r06_kbench_msda_tile_prefetch_ab.log).
+  auto rec_at_batch = [&](int base) { return base < n ? rec[s0 + min(base + lane, n - 1)] : 0; };
+  int s_cur = rec_at_batch(0);
+  int s_nxt = rec_at_batch(64);
+  float2 xy_cur = reinterpret_cast<const float2*>(loc)[s_cur];
+  float aw_cur = attw[s_cur];
   for (int base = 0; base < n; base += 64) {
     // lane k prepares sample base+k: window line of its top-left corner, the four corner weights
     // (times the attention weight) and the offset of its grad_out line
     const bool valid = base + lane < n;
-    const int s = rec[s0 + (valid ? base + lane : 0)];
-    const float2 xy = reinterpret_cast<const float2*>(loc)[s];
-    const float aw = valid ? attw[s] * gm.scale : 0.f;   // (merged queue entries: grad_out / Qn rides on the weight)
+    const int s = s_cur;
+    const float2 xy = xy_cur;
+    const float aw = valid ? aw_cur * gm.scale : 0.f;    // (merged queue entries: grad_out / Qn rides on the weight)
+    // next batch's operands (their sample indices arrived during the previous batch), and the indices after them
+    s_cur = s_nxt;
+    if (base + 64 < n) {
+      xy_cur = reinterpret_cast<const float2*>(loc)[s_cur];
+      aw_cur = attw[s_cur];
+    }
+    s_nxt = rec_at_batch(base + 128);
     const float x = pix(xy.x, Wl), y = pix(xy.y, Hl);
     const int h0 = (int)floorf(y), w0 = (int)floorf(x);
     const float lh = y - h0, lw = x - w0;
@@ -740,35 +763,35 @@ __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     // one word per sample for the v_readlane hand-off: byte offset of its grad_out line (a multiple of 128) | window line
     const int pack = ((int)gm.at(s / LP) * (kCh * 4)) | line;
     __builtin_amdgcn_wave_barrier();
-    // groups of 8 samples, software-pipelined by hand: the weight pairs and grad_out lines of group k+1 are
+    // groups of kGrp samples, software-pipelined by hand: the weight pairs and grad_out lines of group k+1 are
     // requested before the window updates of group k (samples past the end of the chunk carry zero weights)
-    float g[8], gn[8];
-    float2 a[8], an[8];
+    float g[kGrp], gn[kGrp];
+    float2 a[kGrp], an[kGrp];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kGrp; ++u) {
       g[u] = go_one(go_rsrc, ch * 4, __builtin_amdgcn_readlane(pack, u) & ~127);
       a[u] = par[2 * u];                               // (top, bottom) weight of this lane's column
     }
 #pragma unroll
-    for (int j0 = 0; j0 < 64; j0 += 8) {
-      if (j0 + 8 < 64) {
+    for (int j0 = 0; j0 < 64; j0 += kGrp) {
+      if (j0 + kGrp < 64) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = (j0 + 8 + u) & 63;
+        for (int u = 0; u < kGrp; ++u) {
+          const int j = (j0 + kGrp + u) & 63;
           gn[u] = go_one(go_rsrc, ch * 4, __builtin_amdgcn_readlane(pack, j) & ~127);
           an[u] = par[2 * j];
         }
       }
       __builtin_amdgcn_sched_barrier(0);               // keep the requests above ahead of the updates below
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kGrp; ++u) {
         float* p = wq + (__builtin_amdgcn_readlane(pack, j0 + u) & 127) * kCh;
         const float t0 = p[0], t1 = p[kWin * kCh];
         p[0] = t0 + a[u].x * g[u];
         p[kWin * kCh] = t1 + a[u].y * g[u];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { g[u] = gn[u]; a[u] = an[u]; }
+      for (int u = 0; u < kGrp; ++u) { g[u] = gn[u]; a[u] = an[u]; }
     }
   }
   // flush: window line i = (row r, column c) is pixel (ty*kTile + r - 1, tx*kTile + c - 1)
