@@ -397,6 +397,12 @@ size_t vidar_gemm_workspace_bytes(int M, int N, int K, int batch, int precision,
  * order: results are bit-identical.  Returns the previous value. */
 int vidar_gemm_set_variant(int variant);
 
+/* A/B switch of the DCNv2 sampling kernels.  bit 0 (default on): the grad_x gather of vidar_dcn_col2im_f32 (workspace form)
+ * on 3x3 / stride 1 / dilation 1 layers copies, per tap, the window of grad_cols that can reach an 8 x 32 tile of
+ * destination pixels (+ 4 pixels of learned offset) into LDS and gathers from there (sources beyond the window: global
+ * loads); 0 = 4-byte global gathers everywhere (rounds 2-5).  Same sums up to fp32 order.  Values outside 0..1 are ignored.
+ * Returns the previous value. */
+int vidar_dcn_set_variant(int variant);
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
                          int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
                          int dil, void* stream);

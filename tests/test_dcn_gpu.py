@@ -155,3 +155,28 @@ def test_fused_stem_pool_matches_two_kernel_path(shape):
     assert out is not None and out.shape == ref.shape
     assert torch.equal(out, ref)
     assert stem_bn_relu_pool(x.requires_grad_(), bn) is None           # gradients needed -> the caller's two-kernel path
+
+
+@pytest.mark.parametrize("N,C,H,W,std", [(2, 40, 58, 100, 1.5), (1, 33, 29, 50, 4.0), (1, 16, 9, 70, 8.0), (3, 5, 7, 3, 1.0)])
+def test_col2im_lds_window_gather_equals_global_gather(N, C, H, W, std):
+    """the two grad_x gathers of 3x3 / stride 1 layers (vidar_dcn_set_variant): per-tap LDS window of grad_cols + global
+    loads for sources beyond the 4-pixel halo (std 4 / 8: most of them) against 4-byte global gathers everywhere; NaN and
+    far-outside offsets included (their samples have no entries)"""
+    from vidar_amd._lib import lib
+    from vidar_amd.plugin.backbones import dcn_col2im
+    g = torch.Generator().manual_seed(C + W)
+    x = torch.randn(N, C, H, W, generator=g).cuda()
+    off = torch.randn(N, 18, H, W, generator=g) * std
+    off[0, 4, 0, :] = float("nan"); off[0, 7, -1, -1] = 1e4; off[0, 0, :, 0] = -3.0 * std
+    off = off.cuda()
+    mask = torch.rand(N, 9, H, W, generator=g).cuda()
+    gcols = torch.randn(N, C * 9, H * W, generator=g).cuda()
+    outs = []
+    for variant in (1, 0):
+        prev = lib().vidar_dcn_set_variant(variant)
+        try:
+            outs.append(dcn_col2im(gcols, x, off, mask, 3, 3, 1, 1, 1, H, W, gather=True)[0])
+        finally:
+            lib().vidar_dcn_set_variant(prev)
+    assert torch.isfinite(outs[0]).all()
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-4, atol=1e-5 * max(1.0, float(outs[1].abs().max())))

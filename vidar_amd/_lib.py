@@ -27,6 +27,9 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m vidar_amd.build` "
                 f"(or __graft_entry__.build()); vidar_amd has no CPU fallback")
         _lib = ctypes.CDLL(str(LIB_PATH))
+        dcn = os.environ.get("VIDAR_DCN_VARIANT")                # A/B of the DCNv2 col2im gather (LDS window / global loads)
+        if dcn is not None:
+            _lib.vidar_dcn_set_variant(int(dcn))
         order = os.environ.get("VIDAR_MSDA_ITEM_ORDER")          # A/B of the MSDA gather kernels' item order (tools, bench)
         if order is not None:
             _lib.vidar_msda_set_item_order(int(order))

@@ -342,6 +342,131 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* __r
   for (int c = 0; c < nc; ++c) grad_x[((size_t)n * g.C + c0 + c) * HW + pix] = acc[c];
 }
 
+// ---------------------------------------------------------------------------------------------
+// grad wrt input, gather through an LDS window (round 6; 3x3 / stride 1 / dilation 1 layers -- all 26 of the backbone's).
+// The gather above reads `grad_cols` with one 4-byte load per (entry, channel) and lane; with learned offsets the sources
+// of neighbouring destination pixels are no longer neighbours, a wave instruction touches 10-20 cache lines for 256
+// useful bytes and the kernel runs at the L2's line rate: 150 us per call on integer offsets, 445 us in the trained-like
+// step, 1.2 ms on i.i.d. 1.5-pixel offsets (N = 6, C = 256, 58 x 100).  Here a workgroup owns a 16 x 32 tile of destination
+// pixels (2 rows per thread) and 8 channels; per tap it copies the window of `grad_cols` that can reach the tile -- tile + 1
+// (bilinear footprint) + kGHalo pixels of learned offset on every side -- into LDS with coalesced row segments and gathers
+// from LDS (one ds_read_b32 per entry and channel, 8 channels behind one address); an entry whose source lies outside the
+// window (|offset| > kGHalo) takes the global load.  Measured (kernel alone, same shape): 245 us on integer offsets, 360 us on
+// smooth 1.5-pixel offsets, 270 us in the step (-4.5 ms per step).  What the sweep said (profiles/
+// r06_kbench_dcn_col2im_lds_gather.log): the copy into LDS is 2/3 of the kernel and is bound by its instruction count, not by
+// HBM (8 x 32, 16 x 32 and 32 x 32 tiles -- 3.1 x / 2.3 x / 1.8 x the column matrix -- take 274 / 245 / 311 us; float4 pieces
+// of rows, dword aligned on the global side, 1.5 x slower than 4-byte loads; a 6-pixel halo 13 % slower than 4 or 5).
+// ---------------------------------------------------------------------------------------------
+#ifndef VIDAR_DCN_GRY
+#define VIDAR_DCN_GRY 2
+#endif
+#ifndef VIDAR_DCN_GLC
+#define VIDAR_DCN_GLC 8
+#endif
+constexpr int kGRY = VIDAR_DCN_GRY;           // destination rows per thread (rows ry, ry + 8, ...)
+constexpr int kGTH = 8 * kGRY, kGTW = 32;     // destination tile: 256 threads x kGRY pixels
+#ifndef VIDAR_DCN_GHALO
+#define VIDAR_DCN_GHALO 5
+#endif
+constexpr int kGHalo = VIDAR_DCN_GHALO;       // learned offset served from LDS, pixels
+constexpr int kGWH = kGTH + 2 * kGHalo + 2;   // source rows of the window
+constexpr int kGWW = kGTW + 2 * kGHalo + 2;   // 42 source columns ...
+constexpr int kGWP = (kGWW + 3) / 4 * 4;      // ... at a pitch of 44
+constexpr int kGWS = kGWH * kGWP;             // floats per channel (32 x 32 tile: 1 848 for 1 024 pixels -- 1.8 x, 8 x 32: 3.1 x)
+constexpr int kGLC = VIDAR_DCN_GLC;           // channels per workgroup (LDS: kGLC * kGWS * 4 bytes = 59 KB)
+constexpr int kGPos = (kGWS + 255) / 256;     // window positions a thread stages per tap
+
+__global__ __launch_bounds__(256) void dcn_col2im_gather_lds_kernel(
+    const float* __restrict__ grad_cols, const int* __restrict__ first, const int* __restrict__ last,
+    const Entry* __restrict__ rec, float* __restrict__ grad_x, Conv g, int tiles_x, float inv_wo) {
+  __shared__ __attribute__((aligned(16))) float s_gc[kGLC * kGWS];
+  constexpr int K = 9;
+  const int P = g.Ho * g.Wo, HW = g.H * g.W;
+  const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int n = blockIdx.z, c0 = blockIdx.y * kGLC, nc = min(kGLC, g.C - c0);
+  const int ry = threadIdx.x / kGTW, rx = threadIdx.x % kGTW;
+  const int dx = txi * kGTW + rx;
+  const size_t KP = (size_t)K * P;
+  const float* gc = grad_cols + ((size_t)n * g.C + c0) * KP;
+  float acc[kGRY][kGLC];
+#pragma unroll
+  for (int k = 0; k < kGRY; ++k)
+#pragma unroll
+    for (int c = 0; c < kGLC; ++c) acc[k][c] = 0.f;
+  for (int t = 0; t < K; ++t) {
+    const int i = t / 3, j = t - i * 3;
+    // source (= output-pixel) coordinates of window position (0, 0): a source row py reaches destination rows
+    // floor(py - pad + i + off) + {0, 1}, so rows dy0 .. dy0 + kGTH - 1 are reached from py in [dy0 + pad - i - 1 - halo, ..]
+    const int wy0 = tyi * kGTH + g.pad - i - kGHalo - 1, wx0 = txi * kGTW + g.pad - j - kGHalo - 1;
+    const float* gct = gc + (size_t)t * P;
+    __syncthreads();                          // the previous tap's gathers are done
+    // staging in rounds of 4 window positions per thread: their 4 x kGLC loads are requested before the first LDS store.
+    // (float4 pieces of rows -- the global side is only dword aligned -- measured 1.5 x SLOWER than these 4-byte loads,
+    //  profiles/r06_kbench_dcn_col2im_lds_gather.log)
+#pragma unroll
+    for (int k0 = 0; k0 < kGPos; k0 += 4) {
+      float v[4][kGLC];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + (k0 + u) * 256;
+        const int r = e / kGWP, cc = e - r * kGWP;
+        const int sy = wy0 + r, sx = wx0 + cc;
+        ok[u] = e < kGWS && sy >= 0 && sy < g.Ho && sx >= 0 && sx < g.Wo && cc < kGWW;
+        const int off = ok[u] ? sy * g.Wo + sx : 0;
+#pragma unroll
+        for (int c = 0; c < kGLC; ++c) v[u][c] = gct[(size_t)(c < nc ? c : 0) * KP + off];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = threadIdx.x + (k0 + u) * 256;
+        if (e < kGWS) {
+#pragma unroll
+          for (int c = 0; c < kGLC; ++c) s_gc[c * kGWS + e] = ok[u] ? v[u][c] : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (dx >= g.W) continue;
+#pragma unroll
+    for (int k = 0; k < kGRY; ++k) {
+      const int dy = tyi * kGTH + ry + 8 * k;
+      if (dy >= g.H) continue;
+      const size_t bin = ((size_t)n * K + t) * HW + dy * g.W + dx;
+      const int e1 = last[bin];
+      // entries of this (tap, destination pixel): the next entry is requested before the current one is used
+      int e = first[bin];
+      Entry nxt = e < e1 ? rec[e] : Entry{0, 0.f};
+      while (e < e1) {
+        const Entry r = nxt;
+        ++e;
+        if (e < e1) nxt = rec[e];
+        const int p = r.src - t * P;
+        const int py = (int)((p + 0.5f) * inv_wo), px = p - py * g.Wo;   // exact: (p + 0.5) / Wo is >= 0.5 / Wo off an integer
+        const int ly = py - wy0, lx = px - wx0;
+        if (ly >= 0 && ly < kGWH && lx >= 0 && lx < kGWW) {
+          const float* q = s_gc + ly * kGWP + lx;
+#pragma unroll
+          for (int c = 0; c < kGLC; ++c) acc[k][c] += r.w * q[c * kGWS];
+        } else {                              // the source sits beyond the halo: rare, from global memory
+          for (int c = 0; c < nc; ++c) acc[k][c] += r.w * gct[(size_t)c * KP + p];
+        }
+      }
+    }
+  }
+  if (dx < g.W) {
+#pragma unroll
+    for (int k = 0; k < kGRY; ++k) {
+      const int dy = tyi * kGTH + ry + 8 * k;
+      if (dy < g.H)
+        for (int c = 0; c < nc; ++c) grad_x[((size_t)n * g.C + c0 + c) * HW + dy * g.W + dx] = acc[k][c];
+    }
+  }
+}
+
+int g_dcn_variant = 1;         // bit 0: col2im gathers through the LDS window kernel where it applies (vidar_dcn_set_variant)
+
 // grad wrt offset and mask: thread per (n, tap, pixel), loop over channels (no atomics)
 // grid: (ceil(P/256), K, N)
 __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(
@@ -441,6 +566,12 @@ inline bool dcn_bad(int N, const Conv& g) {
 
 extern "C" {
 
+int vidar_dcn_set_variant(int variant) {
+  const int prev = g_dcn_variant;
+  if (variant >= 0 && variant <= 1) g_dcn_variant = variant;
+  return prev;
+}
+
 int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask, float* cols, int N,
                          int C, int H, int W, int Ho, int Wo, int kh, int kw, int stride, int pad,
                          int dil, void* stream) {
@@ -490,8 +621,14 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
     // by its own workgroup -- N K workgroups instead of N (a scan per image kept 6 CUs busy for 0.1 ms per call)
     hipLaunchKernelGGL(dcn_revmap_scan_kernel, dim3(N * K), dim3(1024), 0, s, cursor, first, HW, P * 4);
     hipLaunchKernelGGL(dcn_revmap_kernel<true>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
-    hipLaunchKernelGGL(dcn_col2im_gather_kernel, dim3((HW + 255) / 256, (C + kGC - 1) / kGC, N), dim3(256), 0, s,
-                       grad_cols, first, cursor, rec, grad_x, g);
+    if ((g_dcn_variant & 1) && kh == 3 && kw == 3 && stride == 1 && dil == 1 && Ho == H && Wo == W) {
+      const int tiles_x = (W + kGTW - 1) / kGTW, tiles_y = (H + kGTH - 1) / kGTH;
+      hipLaunchKernelGGL(dcn_col2im_gather_lds_kernel, dim3(tiles_x * tiles_y, (C + kGLC - 1) / kGLC, N), dim3(256), 0,
+                         s, grad_cols, first, cursor, rec, grad_x, g, tiles_x, 1.0f / (float)Wo);
+    } else {
+      hipLaunchKernelGGL(dcn_col2im_gather_kernel, dim3((HW + 255) / 256, (C + kGC - 1) / kGC, N), dim3(256), 0, s,
+                         grad_cols, first, cursor, rec, grad_x, g);
+    }
   } else {
     hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)N * C * H * W, s);
     if (e != hipSuccess) return (int)e;
