@@ -494,7 +494,8 @@ def library_switches():
         return prev
     return {"dvr_traversal": peek(L.vidar_dvr_set_traversal, -1), "dvr_sort_min_waves": peek(L.vidar_dvr_set_sort_min_waves, 1024),
             "dvxlr_pad_mode": peek(L.vidar_dvxlr_set_pad_mode, 1), "gemm_variant": peek(L.vidar_gemm_set_variant, 0),
-            "msda_item_order": peek(L.vidar_msda_set_item_order, 1),
+            "msda_item_order": peek(L.vidar_msda_set_item_order, 1), "dcn_variant": peek(L.vidar_dcn_set_variant, 1),
+            "shortcut_accumulate": os.environ.get("VIDAR_SHORTCUT_ACCUMULATE", "1") != "0",
             "gradient_exchange": os.environ.get("VIDAR_DDP", "flat"), "fused_adamw": os.environ.get("VIDAR_FUSED_ADAMW", "1") != "0",
             "conv_offset": os.environ.get("VIDAR_CONV_OFFSET", "lib"), "share_subsample": os.environ.get("VIDAR_SHARE_SUBSAMPLE", "1") != "0"}
 
