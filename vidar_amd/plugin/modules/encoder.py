@@ -170,12 +170,16 @@ class BEVFormerEncoder(TransformerLayerSequence):
             hybird_ref_2d = torch.stack([shift_ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, num_bev_level, 2)
         else:
             hybird_ref_2d = torch.stack([ref_2d, ref_2d], 1).reshape(bs * 2, len_bev, num_bev_level, 2)
+        # TemporalSelfAttention concatenates `value[:bs]` to its query (temporal_self_attention.py:183; "value" = this
+        # stacked tensor, the same one for all six layers).  Sliced ONCE here instead of once per layer: six slice
+        # backwards each zero-fill a [2 bs, Q, C] gradient, copy their half in and add it to the tensor's gradient
+        value_head = prev_bev[:bs] if prev_bev is not None else None
         for lid, layer in enumerate(self.layers):
             output = layer(bev_query, key, value, *args, bev_pos=bev_pos, ref_2d=hybird_ref_2d,
                            ref_3d=ref_3d, bev_h=bev_h, bev_w=bev_w, spatial_shapes=spatial_shapes,
                            level_start_index=level_start_index,
                            reference_points_cam=reference_points_cam, bev_mask=bev_mask,
-                           prev_bev=prev_bev, sca_index=sca_index, sca_plan=plan, **kwargs)
+                           prev_bev=prev_bev, sca_index=sca_index, sca_plan=plan, value_head=value_head, **kwargs)
             bev_query = output
             if self.latent_rendering_lid is not None:
                 if prev_bev is not None and lid in self.latent_rendering_lid:
@@ -183,6 +187,7 @@ class BEVFormerEncoder(TransformerLayerSequence):
                     # the layout is (b0 prev, b0 cur, b1 prev, ...): take every sample's history row
                     hist = prev_bev.view(bs, 2, len_bev, -1)[:, 0]
                     prev_bev = torch.stack([hist, bev_query], 1).reshape(bs * 2, len_bev, -1)
+                    value_head = prev_bev[:bs]
             if self.return_intermediate:
                 intermediate.append(output)
         if self.return_intermediate:

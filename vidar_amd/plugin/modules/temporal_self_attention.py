@@ -63,7 +63,8 @@ class TemporalSelfAttention(nn.Module):
         assert self.num_bev_queue == 2
         H, Qn, L, P = self.num_heads, self.num_bev_queue, self.num_levels, self.num_points
 
-        query = torch.cat([value[:bs], query], -1)          # (sic) first bs rows, see SURVEY App. D.1
+        head = kwargs.get("value_head")                     # the caller's `value[:bs]` of a value shared by several layers
+        query = torch.cat([value[:bs] if head is None else head, query], -1)   # (sic) first bs rows, see SURVEY App. D.1
         value = self.value_proj(value)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
