@@ -355,8 +355,12 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_kernel(const float* __r
 // smooth 1.5-pixel offsets, 270 us in the step (-4.5 ms per step).  What the sweep said (profiles/
 // r06_kbench_dcn_col2im_lds_gather.log): the copy into LDS is 2/3 of the kernel and is bound by its instruction count, not by
 // HBM (8 x 32, 16 x 32 and 32 x 32 tiles -- 3.1 x / 2.3 x / 1.8 x the column matrix -- take 274 / 245 / 311 us; float4 pieces
-// of rows, dword aligned on the global side, 1.5 x slower than 4-byte loads; a 6-pixel halo 13 % slower than 4 or 5).
+// of rows, dword aligned on the global side, 1.5 x slower than 4-byte loads; a 6-pixel halo 13 % slower than 4 or 5;
+// global_load_lds_dword straight into the lane-linear LDS image instead of load + ds_write: 245 -> 237 / 360 -> 328 us, kept).
 // ---------------------------------------------------------------------------------------------
+#ifndef VIDAR_DCN_GLDS
+#define VIDAR_DCN_GLDS 1
+#endif
 #ifndef VIDAR_DCN_GRY
 #define VIDAR_DCN_GRY 2
 #endif
@@ -400,6 +404,27 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_lds_kernel(
     const int wy0 = tyi * kGTH + g.pad - i - kGHalo - 1, wx0 = txi * kGTW + g.pad - j - kGHalo - 1;
     const float* gct = gc + (size_t)t * P;
     __syncthreads();                          // the previous tap's gathers are done
+#if VIDAR_DCN_GLDS
+    // staging straight into LDS (global_load_lds_dword: destination = wave-uniform base + lane x 4 -- window position
+    // e = thread + k * 256 is lane-linear by construction); positions outside the image are never read and stay as they are
+    {
+      const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#pragma unroll
+      for (int k = 0; k < kGPos; ++k) {
+        const int e = threadIdx.x + k * 256;
+        const int r = e / kGWP, cc = e - r * kGWP;
+        const int sy = wy0 + r, sx = wx0 + cc;
+        const bool ok = e < kGWS && sy >= 0 && sy < g.Ho && sx >= 0 && sx < g.Wo && cc < kGWW;
+        const int off = ok ? sy * g.Wo + sx : 0;
+        if (ok) {
+#pragma unroll
+          for (int c = 0; c < kGLC; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gct + (size_t)(c < nc ? c : 0) * KP + off),
+                                             (__attribute__((address_space(3))) void*)(s_gc + c * kGWS + k * 256 + wave * 64), 4, 0, 0);
+        }
+      }
+    }
+#else
     // staging in rounds of 4 window positions per thread: their 4 x kGLC loads are requested before the first LDS store.
     // (float4 pieces of rows -- the global side is only dword aligned -- measured 1.5 x SLOWER than these 4-byte loads,
     //  profiles/r06_kbench_dcn_col2im_lds_gather.log)
@@ -427,6 +452,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_gather_lds_kernel(
         }
       }
     }
+#endif
     __syncthreads();
     if (dx >= g.W) continue;
 #pragma unroll
