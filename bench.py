@@ -835,7 +835,7 @@ def main():
                                    + "5x BEV encode (6 layers TSA+SCA, LatentRendering, bev 200x200) -> head -> "
                                      "ray CE + gumbel render + chamfer -> backward -> clip -> AdamW",
                        "global_batch": world * spg, "rays_per_frame": args.rays_per_frame,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "weights": main_run["weights"]["mode"]},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(dom_name)[0], "traffic_source": pmc_traffic(dom_name)[1],
