@@ -283,3 +283,20 @@ def test_named_recipes_carry_their_dataset_settings():
         cfg = Config.fromfile(str(ref))
         for name, test in (("vidar_1_8_nusc_3future", False), ("vidar_1_8_nusc_3future", True)):
             assert dataset_kwargs(get_config(name), test, cfg) == dataset_kwargs(get_config(name), test)
+
+
+def test_hsv_pair_agrees_with_the_standard_library_formula():
+    """[3P] cv2 is not installed; the BGR<->HSV pair is the published hexcone model, which Python's `colorsys` implements
+    independently: hue / 360, saturation and value agree on random float pixels (both directions), so what stays
+    unpinned is only cv2's choice of scale for float images (H in degrees, S in [0, 1], V in the input's scale)"""
+    import colorsys
+    from vidar_amd.data.augment import bgr2hsv, hsv2bgr
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 255, (40, 3)).astype(np.float32)
+    hsv = bgr2hsv(img[None])[0]
+    for (b, g, r), (h, s, v) in zip(img.astype(np.float64), hsv.astype(np.float64)):
+        hh, ss, vv = colorsys.rgb_to_hsv(r, g, b)
+        assert abs(h / 360.0 - hh) < 1e-5 and abs(s - ss) < 1e-5 and abs(v - vv) < 1e-3
+        rr, gg, bb = colorsys.hsv_to_rgb(hh, ss, vv)
+        back = hsv2bgr(np.array([[[h, s, v]]], np.float32))[0, 0]
+        np.testing.assert_allclose(back, [bb, gg, rr], rtol=0, atol=2e-3)
