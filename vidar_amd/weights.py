@@ -108,9 +108,21 @@ def apply_trained_like(model, batch, seed=0, dcn_offset_px=1.5, dcn_mask_logit=1
             hooks.append(lin.register_forward_pre_hook(pre))
 
     was_training = model.training
+    # the calibration products (F.linear / F.conv2d without the layers' biases) are shapes of their own: keep TunableOp from
+    # spending the warm-up tuning them
+    tuning = None
+    try:
+        import torch.cuda.tunable as tn
+        if torch.cuda.is_available() and tn.is_enabled() and tn.tuning_is_enabled():
+            tuning = tn
+            tn.tuning_enable(False)
+    except (ImportError, RuntimeError):
+        tuning = None
     try:
         model(return_loss=True, **batch)
     finally:
+        if tuning is not None:
+            tuning.tuning_enable(True)
         for h in hooks:
             h.remove()
         model.train(was_training)
