@@ -21,6 +21,19 @@
 
 namespace {
 
+// XCD-aware block order for kernels whose workgroups of one (channel group, image) PLANE re-read each other's cache lines
+// (window halos, neighbouring taps): hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with its
+// own L2, so the T workgroups of a plane would run on 8 different L2s and every shared line would come from HBM up to 8
+// times.  Here XCD k walks planes k, k + 8, ...: linear id L -> xcd = L % 8, j = L / 8, plane = (j / T) * 8 + xcd,
+// tile = j % T; the grid is padded to 8 * T * ceil(planes / 8) and the extra workgroups return.
+struct PlaneTile { int plane, tile; bool ok; };
+__device__ __forceinline__ PlaneTile xcd_plane_tile(int L, int T, int planes) {
+  const int xcd = L & 7, j = L >> 3;
+  const int pl = (j / T) * 8 + xcd;
+  return PlaneTile{pl, j - (j / T) * T, pl < planes};
+}
+inline unsigned xcd_plane_grid(int T, int planes) { return 8u * (unsigned)T * (unsigned)((planes + 7) / 8); }
+
 struct Conv {
   int C, H, W, Ho, Wo, kh, kw, stride, pad, dil;
 };
@@ -166,11 +179,16 @@ __device__ __forceinline__ TapFoot tap_foot(float h, float w, float m, const Con
 __global__ __launch_bounds__(256) void dcn_im2col_pair_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ offset,
                                                               const float* __restrict__ mask,
-                                                              float* __restrict__ cols, Conv g) {
+                                                              float* __restrict__ cols, Conv g, int nimg) {
   const int P = g.Ho * g.Wo, K = g.kh * g.kw;
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  // XCD-aware order: the (P / 256) workgroups of one (channel group, image) read the same kCP input planes through nine
+  // shifted footprints -- on one XCD they share its L2 (FETCH_SIZE of the 24-image call: 4.6 GB for a 142 MB input before)
+  const int cgroups = (g.C + kCP - 1) / kCP;
+  const PlaneTile pt = xcd_plane_tile(blockIdx.x, (P + 255) / 256, cgroups * nimg);
+  if (!pt.ok) return;
+  const int p = pt.tile * 256 + threadIdx.x;
   if (p >= P) return;
-  const int n = blockIdx.z, c0 = blockIdx.y * kCP, nc = min(kCP, g.C - c0);
+  const int n = pt.plane / cgroups, c0 = (pt.plane - n * cgroups) * kCP, nc = min(kCP, g.C - c0);
   const int py = p / g.Wo, px = p % g.Wo;
   const size_t plane = (size_t)g.H * g.W, KP = (size_t)K * P;
   const char* im = reinterpret_cast<const char*>(x + ((size_t)n * g.C + c0) * plane);       // wave-uniform bases
@@ -382,12 +400,17 @@ constexpr int kGPos = (kGWS + 255) / 256;     // window positions a thread stage
 
 __global__ __launch_bounds__(256) void dcn_col2im_gather_lds_kernel(
     const float* __restrict__ grad_cols, const int* __restrict__ first, const int* __restrict__ last,
-    const Entry* __restrict__ rec, float* __restrict__ grad_x, Conv g, int tiles_x, float inv_wo) {
+    const Entry* __restrict__ rec, float* __restrict__ grad_x, Conv g, int tiles_x, int tiles_y, int nimg, float inv_wo) {
   __shared__ __attribute__((aligned(16))) float s_gc[kGLC * kGWS];
   constexpr int K = 9;
   const int P = g.Ho * g.Wo, HW = g.H * g.W;
-  const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-  const int n = blockIdx.z, c0 = blockIdx.y * kGLC, nc = min(kGLC, g.C - c0);
+  // XCD-aware order: the tiles of one (channel group, image) share their window halos (and the 128-byte lines the
+  // 176-byte row pieces straddle) through ONE L2
+  const int cgroups = (g.C + kGLC - 1) / kGLC;
+  const PlaneTile pt = xcd_plane_tile(blockIdx.x, tiles_x * tiles_y, cgroups * nimg);
+  if (!pt.ok) return;
+  const int tile = pt.tile, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+  const int n = pt.plane / cgroups, c0 = (pt.plane - n * cgroups) * kGLC, nc = min(kGLC, g.C - c0);
   const int ry = threadIdx.x / kGTW, rx = threadIdx.x % kGTW;
   const int dx = txi * kGTW + rx;
   const size_t KP = (size_t)K * P;
@@ -500,6 +523,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_coord_kernel(
     const float* __restrict__ offset, const float* __restrict__ mask,
     float* __restrict__ grad_offset, float* __restrict__ grad_mask, Conv g) {
   const int P = g.Ho * g.Wo, K = g.kh * g.kw;
+  // (the XCD-aware order of the other kernels -- the K workgroups of a pixel block on one XCD -- measured 8 % slower here)
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const int t = blockIdx.y, n = blockIdx.z;
@@ -607,8 +631,8 @@ int vidar_dcn_im2col_f32(const float* x, const float* offset, const float* mask,
   if (N == 0) return 0;
   if (kh * kw > kMaxTaps) return VIDAR_ERR_BAD_ARG;
   if (W >= 2)
-    hipLaunchKernelGGL(dcn_im2col_pair_kernel, dim3((Ho * Wo + 255) / 256, (C + kCP - 1) / kCP, N), dim3(256),
-                       0, (hipStream_t)stream, x, offset, mask, cols, g);
+    hipLaunchKernelGGL(dcn_im2col_pair_kernel, dim3(xcd_plane_grid((Ho * Wo + 255) / 256, ((C + kCP - 1) / kCP) * N)), dim3(256),
+                       0, (hipStream_t)stream, x, offset, mask, cols, g, N);
   else
     hipLaunchKernelGGL(dcn_im2col_kernel, dim3((Ho * Wo + 255) / 256, (C + kCG - 1) / kCG, N), dim3(256),
                        0, (hipStream_t)stream, x, offset, mask, cols, g);
@@ -649,8 +673,8 @@ int vidar_dcn_col2im_f32(const float* grad_cols, const float* x, const float* of
     hipLaunchKernelGGL(dcn_revmap_kernel<true>, rgrid, dim3(256), 0, s, offset, mask, cursor, rec, g);
     if ((g_dcn_variant & 1) && kh == 3 && kw == 3 && stride == 1 && dil == 1 && Ho == H && Wo == W) {
       const int tiles_x = (W + kGTW - 1) / kGTW, tiles_y = (H + kGTH - 1) / kGTH;
-      hipLaunchKernelGGL(dcn_col2im_gather_lds_kernel, dim3(tiles_x * tiles_y, (C + kGLC - 1) / kGLC, N), dim3(256), 0,
-                         s, grad_cols, first, cursor, rec, grad_x, g, tiles_x, 1.0f / (float)Wo);
+      hipLaunchKernelGGL(dcn_col2im_gather_lds_kernel, dim3(xcd_plane_grid(tiles_x * tiles_y, ((C + kGLC - 1) / kGLC) * N)), dim3(256), 0,
+                         s, grad_cols, first, cursor, rec, grad_x, g, tiles_x, tiles_y, N, 1.0f / (float)Wo);
     } else {
       hipLaunchKernelGGL(dcn_col2im_gather_kernel, dim3((HW + 255) / 256, (C + kGC - 1) / kGC, N), dim3(256), 0, s,
                          grad_cols, first, cursor, rec, grad_x, g);
