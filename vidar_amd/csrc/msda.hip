@@ -556,7 +556,9 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
   const int LP = L * P;
   for (int i = threadIdx.x; i < ntl; i += kThreads) s_hist[i] = 0;
   __syncthreads();
-  const int64_t gbin0 = ((int64_t)b * t.T + t.toff[l]) * H + h;    // bin = gbin0 + tile * H
+  // bins are (batch element, head, level, tile): all tiles of one (batch element, head) GROUP are consecutive, so the
+  // chunk table lists a group's chunks together and the accumulate kernel can hand whole groups to one XCD
+  const int64_t gbin0 = ((int64_t)b * H + h) * t.T + t.toff[l];    // bin = gbin0 + tile
   int tile_of[kBinSamples];
   for (int i0 = 0; i0 < n; i0 += kThreads * kBinSamples) {
 #pragma unroll
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
     // reserve a run of record slots per touched tile (the cursor was initialised with the bin starts)
     for (int i = threadIdx.x; i < ntl; i += kThreads) {
       const int c = s_hist[i];
-      if (c) s_hist[i] = atomicAdd(counts + gbin0 + (int64_t)i * H, c);    // the LDS counter becomes the cursor
+      if (c) s_hist[i] = atomicAdd(counts + gbin0 + i, c);    // the LDS counter becomes the cursor
     }
     __syncthreads();
 #pragma unroll
@@ -596,7 +598,7 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
   __syncthreads();
   for (int i = threadIdx.x; i < ntl; i += kThreads) {
     const int c = s_hist[i];
-    if (c) atomicAdd(counts + gbin0 + (int64_t)i * H, c);
+    if (c) atomicAdd(counts + gbin0 + i, c);
   }
 }
 
@@ -610,7 +612,7 @@ constexpr int kScanPer = 8;                            // consecutive bins per t
 constexpr int kScanSlab = kScanThreads * kScanPer;
 __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
     const int64_t* __restrict__ shapes, const int* __restrict__ counts, int* __restrict__ cursor,
-    int4* __restrict__ desc, int* __restrict__ n_chunks, int B, int H, int L) {
+    int4* __restrict__ desc, int* __restrict__ n_chunks, int* __restrict__ group_start, int B, int H, int L) {
   __shared__ LevelTab t;
   __shared__ int s_wsum[kScanThreads / 64], s_wchk[kScanThreads / 64];
   build_tab(t, shapes, L);
@@ -655,15 +657,16 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
     if (w < wave) { ws += a; wk += q; }
   }
   int s = carry_s + ws + xs - ts, kk = carry_k + wk + xk - tk;
-  // (head, tile, level, batch element) of this thread's first bin by division ONCE, then counted up
+  // (tile, level, head, batch element) of this thread's first bin by division ONCE, then counted up
   int bin = base + threadIdx.x * kPer;
-  int h = bin % H, tt = bin / H, b = tt / t.T, tl = tt - b * t.T;
+  int tl = bin % t.T, bh = bin / t.T, h = bh % H, b = bh / H;
   int l = 0;
   while (l + 1 < L && t.toff[l + 1] <= tl) ++l;
   int ty = (tl - t.toff[l]) / t.ntx[l], tx = (tl - t.toff[l]) - ty * t.ntx[l];
 #pragma unroll
   for (int j = 0; j < kPer; ++j, ++bin) {
     if (bin < nbins) {
+      if (tl == 0) group_start[b * H + h] = kk;        // first chunk of the (batch element, head) group
       cursor[bin] = s;
       for (int i = 0; i < c[j]; i += kChunk) {
         desc[2 * kk] = make_int4(s + i, min(kChunk, c[j] - i), l, b);
@@ -672,14 +675,17 @@ __global__ __launch_bounds__(kScanThreads) void msda_bin_scan_kernel(
       }
       s += c[j];
     }
-    if (++h == H) {                                      // next tile
-      h = 0; ++tl;
-      if (++tx == t.ntx[l]) { tx = 0; ++ty; }
-      if (tl == t.T) { tl = 0; ++b; l = 0; tx = ty = 0; }
-      else if (l + 1 < L && tl == t.toff[l + 1]) { ++l; tx = ty = 0; }
-    }
+    ++tl;                                                // next tile
+    if (++tx == t.ntx[l]) { tx = 0; ++ty; }
+    if (tl == t.T) {                                     // next (batch element, head) group
+      tl = 0; l = 0; tx = ty = 0;
+      if (++h == H) { h = 0; ++b; }
+    } else if (l + 1 < L && tl == t.toff[l + 1]) { ++l; tx = ty = 0; }
   }
-  if (threadIdx.x == 0 && base + kScanSlab >= nbins) *n_chunks = carry_k + tot_k;        // the last slab
+  if (threadIdx.x == 0 && base + kScanSlab >= nbins) {   // the last slab
+    *n_chunks = carry_k + tot_k;
+    group_start[B * H] = carry_k + tot_k;
+  }
 }
 
 // Accumulate kernel.  One chunk (<= kChunk records of one destination tile) per wave: the wave accumulates the tile's
@@ -711,13 +717,26 @@ __device__ __forceinline__ float go_one(__amdgpu_buffer_rsrc_t rsrc, int voff, i
 __global__ __launch_bounds__(64 * kTWaves) void msda_bwd_tile_kernel(
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi, const float* __restrict__ loc,
     const float* __restrict__ attw, const float* __restrict__ grad_out, float* __restrict__ grad_value,
-    const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ n_chunks, int Nv,
+    const int* __restrict__ rec, const int4* __restrict__ desc, const int* __restrict__ group_start, int n_groups, int Nv,
     int H, int L, int P, int go_bytes, GoMap gm) {
   __shared__ __attribute__((aligned(16))) float s_win[kTWaves][kWinLines * kCh];
   __shared__ float4 s_par[kTWaves][64];                // per wave and sample: {top-left, bottom-left, top-right, bottom-right}
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int chunk = blockIdx.x * kTWaves + wave;
-  if (chunk >= *n_chunks) return;                      // wave-uniform
+  // XCD-affine chunk assignment (round 6).  Every sample of a (batch element, head) group reads that group's grad_out
+  // lines ([b, q, h*32 .. h*32+31]: exactly one 128-byte line per query) -- ~32 times per line, from different tiles.
+  // Workgroups are dealt round-robin to the 8 XCDs; with chunks assigned in table order every XCD's L2 ended up fetching
+  // nearly ALL of grad_out (FETCH_SIZE 600 MB against 235 MB compulsory, profiles/r05_pmc_msda_sca_coherent_nq7680).
+  // Group g belongs to XCD g % 8: the workgroups of XCD k = blockIdx % 8 walk the chunks of groups k, k + 8, ... in order.
+  int chunk = -1;
+  {
+    int c = (int)(blockIdx.x >> 3) * kTWaves + wave;   // index among this XCD's chunks (wave-uniform)
+    for (int g = (int)(blockIdx.x & 7); g < n_groups; g += 8) {
+      const int g0 = group_start[g], cnt = group_start[g + 1] - g0;
+      if (c < cnt) { chunk = g0 + c; break; }
+      c -= cnt;
+    }
+  }
+  if (chunk < 0) return;                               // wave-uniform
   const int4 d0 = desc[2 * chunk], d1 = desc[2 * chunk + 1];
   const int s0 = d0.x, n = d0.y, l = d0.z, b = d0.w, h = d1.x, ty = d1.y, tx = d1.z;
   const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
@@ -917,12 +936,14 @@ __global__ __launch_bounds__(kThreads) void msda_bwd_locw_kernel(
   }
 }
 
-// workspace layout of the binned backward (all int32): [counts: nbins_bound][cursor: nbins_bound][n_chunks: 4]
+// workspace layout of the binned backward (all int32): [counts: nbins_bound][cursor: nbins_bound][n_chunks: 4][group starts: B*H+1]
 // [chunk table: 4 * max_chunks][records: n_samples].  The level shapes live on the device, so the host
 // sizes the tables from a bound (bin_plan).
 struct BinPlan {
   int64_t n_samples, nbins_bound, max_chunks, tiles_bound;
-  size_t off_cursor, off_chunks, off_desc, off_rec, bytes;
+  size_t off_cursor, off_chunks, off_groups, off_desc, off_rec, bytes;
+  int n_groups;
+  int64_t xcd_chunks;          // bound on the chunks of the groups one XCD walks
   bool ok;
 };
 inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
@@ -934,7 +955,11 @@ inline BinPlan bin_plan(int B, int Nv, int H, int Nq, int L, int P) {
   p.max_chunks = p.n_samples / kChunk + p.nbins_bound;
   p.off_cursor = (sizeof(int) * (size_t)p.nbins_bound + 15) & ~(size_t)15;      // [counts][cursor]: 16-byte aligned tables
   p.off_chunks = 2 * p.off_cursor;
-  p.off_desc = p.off_chunks + 16;
+  p.off_groups = p.off_chunks + 16;                    // first chunk of every (batch element, head) group, + the total
+  p.n_groups = B * H;
+  p.off_desc = (p.off_groups + sizeof(int) * ((size_t)p.n_groups + 1) + 15) & ~(size_t)15;
+  // a group holds Nq * L * P samples in at most tiles_bound bins: XCD k walks groups k, k + 8, ...
+  p.xcd_chunks = (int64_t)((p.n_groups + 7) / 8) * ((int64_t)Nq * L * P / kChunk + p.tiles_bound);
   p.off_rec = p.off_desc + 32 * (size_t)p.max_chunks;
   p.bytes = p.off_rec + sizeof(int) * (size_t)p.n_samples;
   p.ok = L <= kMaxL && p.n_samples > 0 && p.n_samples < (1ll << 31) &&
@@ -1025,6 +1050,7 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     int* counts = (int*)ws;
     int* cursor = (int*)(ws + p.off_cursor);
     int* n_chunks = (int*)(ws + p.off_chunks);
+    int* group_start = (int*)(ws + p.off_groups);
     int4* desc = (int4*)(ws + p.off_desc);
     int* rec = (int*)(ws + p.off_rec);
     hipError_t e = hipMemsetAsync(counts, 0, p.off_desc, s);
@@ -1035,13 +1061,14 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
                        counts, rec, H, Nq, L, P);
     const int nslabs = (int)((p.nbins_bound + kScanSlab - 1) / kScanSlab);
     hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(nslabs), dim3(kScanThreads), 0, s, spatial_shapes, counts, cursor, desc,
-                       n_chunks, B, H, L);
+                       n_chunks, group_start, B, H, L);
     hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
                        cursor, rec, H, Nq, L, P);
-    const int tgrid = (int)((p.max_chunks + kTWaves - 1) / kTWaves);
+    // 8 interleaved sequences of workgroups, one per XCD, each long enough for the chunks its groups can have
+    const unsigned tgrid = 8u * (unsigned)((p.xcd_chunks + kTWaves - 1) / kTWaves);
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
-                       level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, n_chunks,
-                       Nv, H, L, P, (int)(n_items / gm.Qn * kCh * 4), gm);
+                       level_start_index, sampling_loc, attn_weight, grad_out, grad_value, rec, desc, group_start,
+                       p.n_groups, Nv, H, L, P, (int)(n_items / gm.Qn * kCh * 4), gm);
     int nblocks, grid;
     gather_grid(n_items, H, nblocks, grid);
     const size_t lds = rec_lds_bytes(L * P);
