@@ -537,28 +537,36 @@ __device__ __forceinline__ int sample_tile(const LevelTab& t, const float* __res
 // tiles serialise).  So a workgroup owns kBinQ consecutive queries of ONE (batch, head, level) plane --
 // its samples can only fall into that level's tiles -- histograms them in LDS and touches the global
 // counters once per (workgroup, touched tile).
-constexpr int kBinQ = 512;                     // queries per workgroup
+// queries per workgroup of the binning passes: ~4 096 samples (one register-resident batch of kThreads x kBinSamples) --
+// 128 queries for SpatialCrossAttention (L * P = 32), 512 for the one-level shapes (measured: 128 / 256 / 512 queries give
+// 1.278 / 1.287 / 1.304 ms on the SCA backward and 0.382 / 0.349 / 0.342 ms on TemporalSelfAttention's)
+inline int bin_queries(int L, int P) {
+  const int q = 4096 / (L * P);
+  return q < 64 ? 64 : (q > 512 ? 512 : q);
+}
 constexpr int kBinSamples = 16;                // samples per thread held in registers (fill pass)
 constexpr int kMaxTilesLds = 16000;            // LDS histogram capacity: 2 x 4 B x 16000 + the level table < 160 KB
 
 template <bool FILL>
 __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
     const int64_t* __restrict__ shapes, const float* __restrict__ loc, int* __restrict__ counts,
-    int* __restrict__ rec, int H, int Nq, int L, int P) {
+    int* __restrict__ rec, int H, int Nq, int L, int P, int kBinQ) {
   extern __shared__ int s_hist[];              // [ntl] counts; (FILL) then the per-tile record cursors
   __shared__ LevelTab t;
   build_tab(t, shapes, L);
-  const int plane = blockIdx.y;                // (b * H + h) * L + l
-  const int l = plane % L, h = (plane / L) % H, b = plane / L / H;
-  const int ntl = t.ntx[l] * ((t.Hl[l] >> kTileShift) + 1);
+  // a workgroup owns kBinQ queries of one (batch element, head) with ALL their levels: the L * P locations of a
+  // (query, head) are 256 contiguous bytes, read once as whole lines (one workgroup per level fetched every line twice:
+  // FETCH_SIZE 189 MB per pass for the 94 MB of locations)
+  const int h = blockIdx.y % H, b = blockIdx.y / H;
+  const int ntl = t.T;                         // tiles of all levels
   const int q0 = blockIdx.x * kBinQ, nq = min(kBinQ, Nq - q0);
-  const int n = nq * P;                        // samples of this workgroup
   const int LP = L * P;
+  const int n = nq * LP;                       // samples of this workgroup
   for (int i = threadIdx.x; i < ntl; i += kThreads) s_hist[i] = 0;
   __syncthreads();
   // bins are (batch element, head, level, tile): all tiles of one (batch element, head) GROUP are consecutive, so the
   // chunk table lists a group's chunks together and the accumulate kernel can hand whole groups to one XCD
-  const int64_t gbin0 = ((int64_t)b * H + h) * t.T + t.toff[l];    // bin = gbin0 + tile
+  const int64_t gbin0 = ((int64_t)b * H + h) * t.T;                // bin = gbin0 + toff[level] + tile
   int tile_of[kBinSamples];
   for (int i0 = 0; i0 < n; i0 += kThreads * kBinSamples) {
 #pragma unroll
@@ -566,9 +574,9 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
       const int i = i0 + u * kThreads + threadIdx.x;
       int tl = -1;
       if (i < n) {
-        const int ql = i / P, p = i - ql * P;
-        tl = sample_tile(t, loc, (((int64_t)b * Nq + q0 + ql) * H + h) * LP + l * P + p, l);
-        if (tl >= 0) atomicAdd(s_hist + tl, 1);
+        const int ql = i / LP, lp = i - ql * LP, l = lp / P;
+        tl = sample_tile(t, loc, (((int64_t)b * Nq + q0 + ql) * H + h) * LP + lp, l);
+        if (tl >= 0) { tl += t.toff[l]; atomicAdd(s_hist + tl, 1); }
       }
       tile_of[u] = tl;
     }
@@ -585,9 +593,8 @@ __global__ __launch_bounds__(kThreads) void msda_bin_kernel(
       const int i = i0 + u * kThreads + threadIdx.x;
       const int tl = tile_of[u];
       if (tl >= 0) {
-        const int ql = i / P, p = i - ql * P;
-        rec[atomicAdd(s_hist + tl, 1)] =
-            (int)((((int64_t)b * Nq + q0 + ql) * H + h) * LP + l * P + p);
+        const int ql = i / LP, lp = i - ql * LP;
+        rec[atomicAdd(s_hist + tl, 1)] = (int)((((int64_t)b * Nq + q0 + ql) * H + h) * LP + lp);
       }
     }
     __syncthreads();
@@ -1055,15 +1062,16 @@ static int msda_bwd_launch(const float* value, const int64_t* spatial_shapes,
     int* rec = (int*)(ws + p.off_rec);
     hipError_t e = hipMemsetAsync(counts, 0, p.off_desc, s);
     if (e != hipSuccess) return (int)e;
-    const dim3 bgrid((Nq + kBinQ - 1) / kBinQ, B * H * L);
+    const int binq = bin_queries(L, P);
+    const dim3 bgrid((Nq + binq - 1) / binq, B * H);
     const size_t blds = sizeof(int) * (size_t)p.tiles_bound;
     hipLaunchKernelGGL(msda_bin_kernel<false>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
-                       counts, rec, H, Nq, L, P);
+                       counts, rec, H, Nq, L, P, binq);
     const int nslabs = (int)((p.nbins_bound + kScanSlab - 1) / kScanSlab);
     hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(nslabs), dim3(kScanThreads), 0, s, spatial_shapes, counts, cursor, desc,
                        n_chunks, group_start, B, H, L);
     hipLaunchKernelGGL(msda_bin_kernel<true>, bgrid, dim3(kThreads), blds, s, spatial_shapes, sampling_loc,
-                       cursor, rec, H, Nq, L, P);
+                       cursor, rec, H, Nq, L, P, binq);
     // 8 interleaved sequences of workgroups, one per XCD, each long enough for the chunks its groups can have
     const unsigned tgrid = 8u * (unsigned)((p.xcd_chunks + kTWaves - 1) / kTWaves);
     hipLaunchKernelGGL(msda_bwd_tile_kernel, dim3(tgrid), dim3(64 * kTWaves), 0, s, spatial_shapes,
